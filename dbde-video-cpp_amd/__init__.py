@@ -1,0 +1,333 @@
+"""dbde_video_cpp_amd -- Python doorway to the MI355X DBDE codec (libdbde_hip.so).
+
+This is plumbing, not the product: every function is a ctypes call into the C-ABI declared
+in include/dbde_hip.h.  PyTorch is used only for what it is good at here -- device memory
+(`tensor.data_ptr()`), streams and `torch.distributed`.  Method names follow the reference's
+dbde_util.h (pack_frame, unpack_frame, pack_8x8, ...), so tests read like the reference's.
+
+There is no CPU fallback.  If the in-tree library is missing, importing raises; if no
+gfx950 device is usable, `Codec()` raises.
+
+The directory is called `dbde-video-cpp_amd`; import it as `dbde_video_cpp_amd` (the
+repository root carries a one-file loader of that name).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+try:  # torch first: its bundled libamdhip64.so.7 must be the one HIP runtime in the process
+    import torch
+except Exception:  # pragma: no cover - host-only use of the header helpers
+    torch = None
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libdbde_hip.so")
+SHIM_PATH = os.path.join(PKG_DIR, "libdbde_util_hip.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_CAPACITY, ERR_DEVICE = 0, -1, -2, -3, -4
+
+MODES = {"noise8": 0, "mixed": 1, "flat": 2, "smooth": 3}
+
+# every symbol include/dbde_hip.h declares (tests/test_capi_symbols.py checks the export list)
+C_ABI_SYMBOLS = [
+    "dbde_hip_create", "dbde_hip_destroy", "dbde_hip_sync", "dbde_hip_last_error", "dbde_hip_device_arch",
+    "dbde_hip_max_frame_bytes", "dbde_hip_image_bytes",
+    "dbde_hip_encode_frames", "dbde_hip_decode_frames", "dbde_hip_index_stream", "dbde_hip_synth_frames",
+    "dbde_hip_pack_8x8", "dbde_hip_pack_8x8_partial", "dbde_hip_pack_image", "dbde_hip_pack_frame",
+    "dbde_hip_unpack_8x8", "dbde_hip_unpack_8x8_partial", "dbde_hip_unpack_image", "dbde_hip_unpack_frame",
+    "dbde_hip_pack_frame_header", "dbde_hip_pack_video_header",
+    "dbde_hip_unpack_frame_header", "dbde_hip_unpack_video_header",
+    "dbde_hip_timing_enable", "dbde_hip_timing_read",
+]
+
+
+def build(verbose=False):
+    """Compile the HIP library and the dbde_util.h shim in-tree (hipcc --offload-arch=gfx950)."""
+    r = subprocess.run(["make", "-C", os.path.join(PKG_DIR, "csrc")], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError("building libdbde_hip.so failed")
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [("u64s", C.c_uint32), ("index", C.c_uint64), ("elapsed_ns", C.c_uint64)]
+
+
+class VideoHeader(C.Structure):
+    _fields_ = [("u64s", C.c_uint32), ("height", C.c_uint64), ("width", C.c_uint64), ("frame_hz", C.c_double)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("header", FrameHeader), ("consumed", C.c_uint64)]
+
+
+u8p = C.POINTER(C.c_uint8)
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i, u64, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
+    L.dbde_hip_create.restype = i
+    L.dbde_hip_create.argtypes = [i, vp, C.POINTER(vp)]
+    L.dbde_hip_destroy.restype = None
+    L.dbde_hip_destroy.argtypes = [vp]
+    L.dbde_hip_sync.restype = i
+    L.dbde_hip_sync.argtypes = [vp]
+    L.dbde_hip_last_error.restype = C.c_char_p
+    L.dbde_hip_last_error.argtypes = [vp]
+    L.dbde_hip_device_arch.restype = C.c_char_p
+    L.dbde_hip_device_arch.argtypes = [vp]
+    L.dbde_hip_max_frame_bytes.restype = sz
+    L.dbde_hip_max_frame_bytes.argtypes = [i, i]
+    L.dbde_hip_image_bytes.restype = sz
+    L.dbde_hip_image_bytes.argtypes = [i, i, u64]
+    L.dbde_hip_encode_frames.restype = i
+    L.dbde_hip_encode_frames.argtypes = [vp, vp, i, i, i, u64, vp, vp, vp, sz, u64, vp, vp]
+    L.dbde_hip_decode_frames.restype = i
+    L.dbde_hip_decode_frames.argtypes = [vp, vp, sz, vp, i, i, i, vp, vp]
+    L.dbde_hip_index_stream.restype = i
+    L.dbde_hip_index_stream.argtypes = [vp, vp, sz, i, i, i, vp, C.POINTER(i)]
+    L.dbde_hip_synth_frames.restype = i
+    L.dbde_hip_synth_frames.argtypes = [vp, i, u64, u64, i, i, i, vp]
+    L.dbde_hip_pack_8x8.restype = C.c_uint32
+    L.dbde_hip_pack_8x8.argtypes = [vp, vp, i, vp]
+    L.dbde_hip_pack_8x8_partial.restype = C.c_uint32
+    L.dbde_hip_pack_8x8_partial.argtypes = [vp, vp, i, i, i, vp]
+    L.dbde_hip_pack_image.restype = sz
+    L.dbde_hip_pack_image.argtypes = [vp, vp, i, i, vp]
+    L.dbde_hip_pack_frame.restype = sz
+    L.dbde_hip_pack_frame.argtypes = [vp, u64, vp, i, i, vp]
+    L.dbde_hip_unpack_8x8.restype = None
+    L.dbde_hip_unpack_8x8.argtypes = [vp, C.c_uint8, C.c_uint8, vp, sz, vp]
+    L.dbde_hip_unpack_8x8_partial.restype = None
+    L.dbde_hip_unpack_8x8_partial.argtypes = [vp, C.c_uint8, C.c_uint8, vp, sz, i, i, vp]
+    L.dbde_hip_unpack_image.restype = sz
+    L.dbde_hip_unpack_image.argtypes = [vp, vp, i, i, vp]
+    L.dbde_hip_unpack_frame.restype = FrameHeader
+    L.dbde_hip_unpack_frame.argtypes = [vp, C.POINTER(vp), i, i, vp]
+    L.dbde_hip_pack_frame_header.restype = sz
+    L.dbde_hip_pack_frame_header.argtypes = [C.POINTER(FrameHeader), vp]
+    L.dbde_hip_pack_video_header.restype = sz
+    L.dbde_hip_pack_video_header.argtypes = [C.POINTER(VideoHeader), vp]
+    L.dbde_hip_unpack_frame_header.restype = FrameHeader
+    L.dbde_hip_unpack_frame_header.argtypes = [C.POINTER(vp)]
+    L.dbde_hip_unpack_video_header.restype = VideoHeader
+    L.dbde_hip_unpack_video_header.argtypes = [C.POINTER(vp)]
+    L.dbde_hip_timing_enable.restype = i
+    L.dbde_hip_timing_enable.argtypes = [vp, i]
+    L.dbde_hip_timing_read.restype = i
+    L.dbde_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i]
+    _lib = L
+    return L
+
+
+def max_frame_bytes(W, H):
+    return int(lib().dbde_hip_max_frame_bytes(W, H))
+
+
+def tiles(W, H):
+    return ((W + 7) // 8) * ((H + 7) // 8)
+
+
+# ---- header wire format (host only) ------------------------------------------------------
+
+def pack_frame_header(u64s, index, elapsed_ns):
+    out = np.zeros(20, np.uint8)
+    fh = FrameHeader(u64s, index, elapsed_ns)
+    assert lib().dbde_hip_pack_frame_header(C.byref(fh), out.ctypes.data) == 20
+    return out
+
+
+def pack_video_header(u64s, height, width, frame_hz):
+    out = np.zeros(28, np.uint8)
+    vh = VideoHeader(u64s, height, width, frame_hz)
+    assert lib().dbde_hip_pack_video_header(C.byref(vh), out.ctypes.data) == 28
+    return out
+
+
+def unpack_frame_header(packed):
+    buf = np.ascontiguousarray(np.asarray(packed, np.uint8)[:20])
+    cur = C.c_void_p(buf.ctypes.data)
+    fh = lib().dbde_hip_unpack_frame_header(C.byref(cur))
+    return cur.value - buf.ctypes.data, (fh.u64s, fh.index, fh.elapsed_ns)
+
+
+def unpack_video_header(packed):
+    buf = np.ascontiguousarray(np.asarray(packed, np.uint8)[:28])
+    cur = C.c_void_p(buf.ctypes.data)
+    vh = lib().dbde_hip_unpack_video_header(C.byref(cur))
+    return cur.value - buf.ctypes.data, (vh.u64s, vh.height, vh.width, vh.frame_hz)
+
+
+class DbdeError(RuntimeError):
+    pass
+
+
+class Codec:
+    """One C-ABI context: a HIP device + stream.  Not thread-safe (one per thread)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = lib()
+        if torch is None or not torch.cuda.is_available():
+            raise DbdeError("no HIP device visible to PyTorch; the DBDE codec has no CPU path")
+        self.device = torch.device("cuda", device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        self.stream = stream
+        h = C.c_void_p()
+        rc = self.L.dbde_hip_create(device, C.c_void_p(stream.cuda_stream), C.byref(h))
+        if rc != OK or not h.value:
+            raise DbdeError(f"dbde_hip_create failed ({rc}): needs a gfx950 device; no CPU path")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.dbde_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise DbdeError(f"{what} failed ({rc}): {self.L.dbde_hip_last_error(self.h).decode()}")
+
+    @property
+    def arch(self):
+        return self.L.dbde_hip_device_arch(self.h).decode()
+
+    def sync(self):
+        self._check(self.L.dbde_hip_sync(self.h), "dbde_hip_sync")
+
+    # ---- batch API on device tensors ---------------------------------------------------
+    def synth_frames(self, mode, seed, first_frame, n, W, H, out=None):
+        if out is None:
+            out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        m = MODES[mode] if isinstance(mode, str) else mode
+        self._check(self.L.dbde_hip_synth_frames(self.h, m, seed, first_frame, n, W, H, out.data_ptr()),
+                    "dbde_hip_synth_frames")
+        return out
+
+    def alloc_stream(self, W, H, n, slot_stride=0, lead=32):
+        """Device buffer for n worst-case frames.  `lead` bytes are kept in front of the first
+        frame (28-byte video header at lead-28) so that frames start 8-byte aligned."""
+        cap = (n - 1) * slot_stride + max_frame_bytes(W, H) if slot_stride else n * max_frame_bytes(W, H)
+        buf = torch.empty(lead + cap + 64, dtype=torch.uint8, device=self.device)
+        return buf, lead, cap
+
+    def encode_frames(self, images, W, H, n, out, out_offset, capacity, first_index=0, indices=None,
+                      elapsed_ns=None, slot_stride=0, offsets=None, nbytes=None):
+        """images: uint8 device tensor of n*H*W bytes.  Frames are written from
+        out.data_ptr()+out_offset.  Returns (offsets, nbytes) int64 device tensors (per frame)."""
+        if offsets is None:
+            offsets = torch.empty(n, dtype=torch.int64, device=self.device)
+        if nbytes is None:
+            nbytes = torch.empty(n, dtype=torch.int64, device=self.device)
+        rc = self.L.dbde_hip_encode_frames(
+            self.h, images.data_ptr(), W, H, n, first_index,
+            indices.data_ptr() if indices is not None else None,
+            elapsed_ns.data_ptr() if elapsed_ns is not None else None,
+            out.data_ptr() + out_offset, capacity, slot_stride, offsets.data_ptr(), nbytes.data_ptr())
+        self._check(rc, "dbde_hip_encode_frames")
+        return offsets, nbytes
+
+    def decode_frames(self, stream, stream_offset, stream_bytes, offsets, W, H, n, images=None, results=None):
+        """Decodes n frames; frame f starts at stream.data_ptr()+stream_offset+offsets[f]."""
+        if images is None:
+            images = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        if results is None:
+            results = torch.empty((n, 4), dtype=torch.int64, device=self.device)
+        rc = self.L.dbde_hip_decode_frames(self.h, stream.data_ptr() + stream_offset, stream_bytes,
+                                           offsets.data_ptr(), W, H, n, images.data_ptr(), results.data_ptr())
+        self._check(rc, "dbde_hip_decode_frames")
+        return images, results
+
+    def index_stream(self, stream, stream_offset, stream_bytes, W, H, max_frames):
+        offsets = torch.empty(max(max_frames, 1), dtype=torch.int64, device=self.device)
+        n = C.c_int(0)
+        rc = self.L.dbde_hip_index_stream(self.h, stream.data_ptr() + stream_offset, stream_bytes, W, H,
+                                          max_frames, offsets.data_ptr(), C.byref(n))
+        self._check(rc, "dbde_hip_index_stream")
+        return offsets[:n.value], n.value
+
+    @staticmethod
+    def parse_results(results):
+        """results tensor (n,4) int64 -> list of (u64s, index, elapsed_ns, consumed)."""
+        r = results.cpu().numpy().view(np.uint64)
+        return [(int(a) & 0xFFFFFFFF, int(b), int(c), int(d)) for a, b, c, d in r]
+
+    # ---- host-pointer API: the reference's functions -------------------------------------
+    def pack_frame(self, index, image, W, H):
+        src = np.ascontiguousarray(image, np.uint8).reshape(-1)
+        out = np.full(max_frame_bytes(W, H) + 64, 0xEE, np.uint8)
+        n = self.L.dbde_hip_pack_frame(self.h, index, src.ctypes.data, W, H, out.ctypes.data)
+        assert (out[n:] == 0xEE).all(), "wrote past the returned size"
+        return out[:n].copy()
+
+    def pack_image(self, image, W, H):
+        src = np.ascontiguousarray(image, np.uint8).reshape(-1)
+        out = np.full(max_frame_bytes(W, H) + 64, 0xEE, np.uint8)
+        n = self.L.dbde_hip_pack_image(self.h, src.ctypes.data, W, H, out.ctypes.data)
+        assert (out[n:] == 0xEE).all(), "wrote past the returned size"
+        return out[:n].copy()
+
+    def unpack_image(self, packed, W, H, fill=0xEE):
+        img = np.full(W * H, fill, np.uint8)
+        buf = np.concatenate([np.asarray(packed, np.uint8), np.zeros(64, np.uint8)])
+        n = self.L.dbde_hip_unpack_image(self.h, buf.ctypes.data, W, H, img.ctypes.data)
+        return int(n), img.reshape(H, W)
+
+    def unpack_frame(self, packed, W, H, fill=0xEE):
+        img = np.full(W * H, fill, np.uint8)
+        buf = np.concatenate([np.asarray(packed, np.uint8), np.zeros(64, np.uint8)])
+        cur = C.c_void_p(buf.ctypes.data)
+        fh = self.L.dbde_hip_unpack_frame(self.h, C.byref(cur), W, H, img.ctypes.data)
+        return cur.value - buf.ctypes.data, (fh.u64s, fh.index, fh.elapsed_ns), img.reshape(H, W)
+
+    def pack_8x8(self, image, off, stride):
+        out = np.full(64 + 16, 0xEE, np.uint8)
+        code = self.L.dbde_hip_pack_8x8(self.h, image.ctypes.data + off, stride, out.ctypes.data)
+        return int(code), out[:8 * (code >> 8)].copy(), out
+
+    def pack_8x8_partial(self, image, off, stride, rm, dm):
+        out = np.full(64 + 16, 0xEE, np.uint8)
+        code = self.L.dbde_hip_pack_8x8_partial(self.h, image.ctypes.data + off, stride, rm, dm, out.ctypes.data)
+        return int(code), out[:8 * (code >> 8)].copy(), out
+
+    def unpack_8x8(self, depth, minval, packed, stride, canvas, off=0):
+        buf = np.zeros(64 + 8, np.uint8)
+        buf[:len(packed)] = packed
+        self.L.dbde_hip_unpack_8x8(self.h, depth, minval, buf.ctypes.data, stride, canvas.ctypes.data + off)
+        return canvas
+
+    def unpack_8x8_partial(self, depth, minval, packed, stride, rm, dm, canvas, off=0):
+        buf = np.zeros(64 + 8, np.uint8)
+        buf[:len(packed)] = packed
+        self.L.dbde_hip_unpack_8x8_partial(self.h, depth, minval, buf.ctypes.data, stride, rm, dm,
+                                           canvas.ctypes.data + off)
+        return canvas
+
+    # ---- timing hook ------------------------------------------------------------------
+    def timing(self, on=True):
+        self._check(self.L.dbde_hip_timing_enable(self.h, 1 if on else 0), "dbde_hip_timing_enable")
+
+    def timing_read(self, reset=True):
+        ms = (C.c_double * 3)()
+        n = (C.c_uint64 * 3)()
+        self._check(self.L.dbde_hip_timing_read(self.h, ms, n, 1 if reset else 0), "dbde_hip_timing_read")
+        return {"encode": (ms[0], n[0]), "decode_index": (ms[1], n[1]), "decode": (ms[2], n[2])}

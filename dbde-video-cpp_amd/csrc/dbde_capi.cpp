@@ -1,0 +1,561 @@
+// dbde_capi.cpp -- implementation of include/dbde_hip.h (the C-ABI of libdbde_hip.so).
+//
+// Host side only: argument checking, workspace, launches, and the byte marshalling the
+// host-pointer entry points need.  All tile arithmetic is in dbde_kernels.hip; nothing here
+// (or anywhere in this library) computes DBDE on the CPU.
+#include "../../include/dbde_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dbde_kernels.h"
+
+using namespace dbde;
+
+namespace {
+
+struct TimedSpan {
+    hipEvent_t a, b;
+    int kind;
+};
+
+struct Geometry {
+    uint32_t w, h, T, cpf;
+    uint64_t pixels;
+};
+
+}  // namespace
+
+struct dbde_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string arch;
+
+    // look-back workspace: [ctrl: 4 x u32][state: n_chunks x u64], zeroed before every encode
+    void *lb = nullptr;
+    size_t lb_bytes = 0;
+    // decode workspace
+    uint32_t *chunk_off = nullptr;
+    size_t chunk_off_n = 0;
+    uint32_t *frame_ok = nullptr;
+    size_t frame_ok_n = 0;
+    // sticky failure word (device) + scratch
+    uint32_t *sticky = nullptr;
+    uint64_t *scratch64 = nullptr;   // small device scratch: [0..3]
+    // staging for the host-pointer entry points
+    uint8_t *st_img = nullptr;
+    size_t st_img_bytes = 0;
+    uint8_t *st_pack = nullptr;
+    size_t st_pack_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    double acc_ms[3] = {0, 0, 0};
+    uint64_t acc_n[3] = {0, 0, 0};
+};
+
+namespace {
+
+int fail(dbde_hip_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, DBDE_HIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+bool geometry(int W, int H, Geometry &g) {
+    if (W <= 0 || H <= 0) return false;
+    uint64_t w = ((uint64_t)W + 7) / 8, h = ((uint64_t)H + 7) / 8;
+    uint64_t T = w * h;
+    if (T >= (1ull << 27)) return false;   // in-frame payload words must stay below 2^30
+    g.w = (uint32_t)w;
+    g.h = (uint32_t)h;
+    g.T = (uint32_t)T;
+    g.cpf = (uint32_t)((T + kChunkTiles - 1) / kChunkTiles);
+    g.pixels = (uint64_t)W * (uint64_t)H;
+    return true;
+}
+
+template <typename Ptr>
+int grow(dbde_hip_ctx *ctx, Ptr &p, size_t &have, size_t want_elems, size_t elem_bytes) {
+    if (want_elems <= have) return DBDE_HIP_OK;
+    // everything queued may still be using the old block
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (p) HIP_TRY(ctx, hipFree(p));
+    p = nullptr;
+    have = 0;
+    size_t n = want_elems + want_elems / 4 + 64;
+    void *q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, n * elem_bytes));
+    p = reinterpret_cast<Ptr>(q);
+    have = n;
+    return DBDE_HIP_OK;
+}
+
+void span_begin(dbde_hip_ctx *ctx, int kind) {
+    if (!ctx->timing) return;
+    TimedSpan s;
+    s.kind = kind;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    hipEventRecord(s.a, ctx->stream);
+    ctx->spans.push_back(s);
+}
+void span_end(dbde_hip_ctx *ctx) {
+    if (!ctx->timing || ctx->spans.empty()) return;
+    hipEventRecord(ctx->spans.back().b, ctx->stream);
+}
+
+void put32(uint8_t *p, uint32_t v) { for (int i = 0; i < 4; i++) p[i] = (uint8_t)(v >> (8 * i)); }
+void put64(uint8_t *p, uint64_t v) { for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i)); }
+uint32_t get32(const uint8_t *p) { uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)p[i] << (8 * i); return v; }
+uint64_t get64(const uint8_t *p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i); return v; }
+
+int ensure_staging(dbde_hip_ctx *ctx, size_t img_bytes, size_t pack_bytes) {
+    int rc = grow(ctx, ctx->st_img, ctx->st_img_bytes, img_bytes + 64, 1);
+    if (rc) return rc;
+    return grow(ctx, ctx->st_pack, ctx->st_pack_bytes, pack_bytes + 64, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- context ---------------------------------------------------------------------------------
+
+int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out) {
+    if (!out) return DBDE_HIP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DBDE_HIP_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return DBDE_HIP_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DBDE_HIP_ERR_HIP;
+    // kernels are built for gfx950 only; refuse anything else instead of failing at launch
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DBDE_HIP_ERR_HIP;
+    dbde_hip_ctx *ctx = new dbde_hip_ctx;
+    ctx->device = device;
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    ctx->arch = prop.gcnArchName;
+    void *p = nullptr;
+    if (hipMalloc(&p, 64) != hipSuccess) { delete ctx; return DBDE_HIP_ERR_HIP; }
+    ctx->sticky = reinterpret_cast<uint32_t *>(p);
+    ctx->scratch64 = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(p) + 16);
+    if (hipMemsetAsync(p, 0, 64, ctx->stream) != hipSuccess) { hipFree(p); delete ctx; return DBDE_HIP_ERR_HIP; }
+    *out = ctx;
+    return DBDE_HIP_OK;
+}
+
+void dbde_hip_destroy(dbde_hip_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    if (ctx->lb) hipFree(ctx->lb);
+    if (ctx->chunk_off) hipFree(ctx->chunk_off);
+    if (ctx->frame_ok) hipFree(ctx->frame_ok);
+    if (ctx->sticky) hipFree(ctx->sticky);
+    if (ctx->st_img) hipFree(ctx->st_img);
+    if (ctx->st_pack) hipFree(ctx->st_pack);
+    delete ctx;
+}
+
+int dbde_hip_sync(dbde_hip_ctx *ctx) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    uint32_t flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->sticky, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->sticky, 0, 4, ctx->stream));
+        return fail(ctx, DBDE_HIP_ERR_DEVICE, "encode kernel: chunk look-back timed out");
+    }
+    return DBDE_HIP_OK;
+}
+
+const char *dbde_hip_last_error(const dbde_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *dbde_hip_device_arch(const dbde_hip_ctx *ctx) { return ctx ? ctx->arch.c_str() : ""; }
+
+// ---- sizes -----------------------------------------------------------------------------------
+
+size_t dbde_hip_max_frame_bytes(int W, int H) {
+    Geometry g;
+    if (!geometry(W, H, g)) return 0;
+    return 20 + 12 + 66 * (size_t)g.T;
+}
+
+size_t dbde_hip_image_bytes(int W, int H, uint64_t n64) {
+    Geometry g;
+    if (!geometry(W, H, g)) return 0;
+    return 12 + 2 * (size_t)g.T + 8 * (size_t)n64;
+}
+
+// ---- batch encode ----------------------------------------------------------------------------
+
+int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, int H, int n_frames,
+                           uint64_t first_index, const uint64_t *d_indices, const uint64_t *d_elapsed_ns,
+                           uint8_t *d_out, size_t out_capacity, uint64_t slot_stride,
+                           uint64_t *d_frame_offsets, uint64_t *d_frame_bytes) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    Geometry g;
+    if (!d_images || !d_out || n_frames < 0 || !geometry(W, H, g))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
+    if (n_frames == 0) return DBDE_HIP_OK;
+    const uint64_t maxf = 32ull + 66ull * g.T;
+    const uint64_t n_chunks64 = (uint64_t)n_frames * g.cpf;
+    if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: too many chunks in one call");
+    if (slot_stride) {
+        if (slot_stride < maxf) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: slot_stride below the worst case");
+        if ((uint64_t)(n_frames - 1) * slot_stride + maxf > out_capacity)
+            return fail(ctx, DBDE_HIP_ERR_CAPACITY, "encode_frames: out_capacity below the worst case");
+    } else {
+        if ((uint64_t)n_frames * maxf > out_capacity)
+            return fail(ctx, DBDE_HIP_ERR_CAPACITY, "encode_frames: out_capacity below the worst case");
+        // launch-wide running word count is carried in 32 bits
+        if ((uint64_t)n_frames * 8ull * g.T >= (1ull << 32))
+            return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: more than 2^32 payload words possible; split the batch");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    const uint32_t n_chunks = (uint32_t)n_chunks64;
+    const size_t lb_need = 16 + 8 * (size_t)n_chunks;
+    {
+        size_t have = ctx->lb_bytes;
+        uint8_t *p = reinterpret_cast<uint8_t *>(ctx->lb);
+        int rc = grow(ctx, p, have, lb_need, 1);
+        if (rc) return rc;
+        ctx->lb = p;
+        ctx->lb_bytes = have;
+    }
+    const size_t zero_bytes = (lb_need + 15) & ~(size_t)15;
+    span_begin(ctx, 0);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, zero_bytes, ctx->stream));
+
+    EncParams p;
+    p.images = d_images;
+    p.out = d_out;
+    p.frame_offsets = d_frame_offsets;
+    p.frame_bytes = d_frame_bytes;
+    p.indices = d_indices;
+    p.elapsed_ns = d_elapsed_ns;
+    p.first_index = first_index;
+    p.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
+    p.state = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(ctx->lb) + 16);
+    p.sticky = ctx->sticky;
+    p.slot_stride = slot_stride;
+    p.frame_pixels = g.pixels;
+    p.W = W;
+    p.H = H;
+    p.w = g.w;
+    p.h = g.h;
+    p.T = g.T;
+    p.chunks_per_frame = g.cpf;
+    p.n_chunks = n_chunks;
+    const bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
+    const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
+                             (slot_stride % 8 == 0);
+    HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
+    span_end(ctx);
+    return DBDE_HIP_OK;
+}
+
+// ---- batch decode ----------------------------------------------------------------------------
+
+int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes,
+                           const uint64_t *d_frame_offsets, int W, int H, int n_frames, uint8_t *d_images,
+                           dbde_hip_frame_result *d_results) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    Geometry g;
+    if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
+    if (n_frames == 0) return DBDE_HIP_OK;
+    if (g.cpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
+    const uint64_t n_chunks64 = (uint64_t)n_frames * g.cpf;
+    if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64, sizeof(uint32_t));
+    if (rc) return rc;
+    rc = grow(ctx, ctx->frame_ok, ctx->frame_ok_n, (size_t)n_frames, sizeof(uint32_t));
+    if (rc) return rc;
+
+    IdxParams ip;
+    ip.stream = d_stream;
+    ip.frame_offsets = d_frame_offsets;
+    ip.stream_bytes = stream_bytes;
+    ip.chunk_off = ctx->chunk_off;
+    ip.frame_ok = ctx->frame_ok;
+    ip.results = d_results;
+    ip.T = g.T;
+    ip.chunks_per_frame = g.cpf;
+    span_begin(ctx, 1);
+    HIP_TRY(ctx, launch_decode_index(ip, n_frames, ctx->stream));
+    span_end(ctx);
+
+    DecParams p;
+    p.stream = d_stream;
+    p.frame_offsets = d_frame_offsets;
+    p.images = d_images;
+    p.chunk_off = ctx->chunk_off;
+    p.frame_ok = ctx->frame_ok;
+    p.frame_pixels = g.pixels;
+    p.W = W;
+    p.H = H;
+    p.w = g.w;
+    p.h = g.h;
+    p.T = g.T;
+    p.chunks_per_frame = g.cpf;
+    p.n_chunks = (uint32_t)n_chunks64;
+    const bool fast_img = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
+    span_begin(ctx, 2);
+    HIP_TRY(ctx, launch_decode(p, fast_img, ctx->stream));
+    span_end(ctx);
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W, int H,
+                          int max_frames, uint64_t *d_frame_offsets, int *n_found) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    Geometry g;
+    if (!d_stream || !d_frame_offsets || !n_found || max_frames < 0 || !geometry(W, H, g))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "index_stream: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t *d_count = reinterpret_cast<uint32_t *>(ctx->scratch64);
+    HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_count, ctx->stream));
+    uint32_t cnt = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n_found = (int)cnt;
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_synth_frames(dbde_hip_ctx *ctx, int mode, uint64_t seed, uint64_t first_frame, int n_frames,
+                          int W, int H, uint8_t *d_images) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    if (!d_images || W <= 0 || H <= 0 || n_frames < 0 || mode < 0 || mode > 3)
+        return fail(ctx, DBDE_HIP_ERR_ARG, "synth_frames: bad argument");
+    if (n_frames == 0) return DBDE_HIP_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_synth(mode, seed, first_frame, n_frames, W, H, d_images, ctx->stream));
+    return DBDE_HIP_OK;
+}
+
+// ---- host-pointer entry points ---------------------------------------------------------------
+
+// Encodes one host image through the GPU; returns the frame's byte count and leaves the
+// packed frame (header + data) in ctx->st_pack.  0 on failure.
+static size_t encode_one_host(dbde_hip_ctx *ctx, uint64_t index, const uint8_t *image, int W, int H) {
+    Geometry g;
+    if (!ctx || !image || !geometry(W, H, g)) return 0;
+    const size_t maxf = 32 + 66 * (size_t)g.T;
+    if (ensure_staging(ctx, (size_t)g.pixels, maxf)) return 0;
+    if (hipMemcpyAsync(ctx->st_img, image, (size_t)g.pixels, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
+    uint64_t *d_bytes = ctx->scratch64 + 1;
+    if (dbde_hip_encode_frames(ctx, ctx->st_img, W, H, 1, index, nullptr, nullptr, ctx->st_pack, maxf, 0, nullptr,
+                               d_bytes) != DBDE_HIP_OK)
+        return 0;
+    uint64_t nbytes = 0;
+    if (hipMemcpyAsync(&nbytes, d_bytes, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0;
+    if (dbde_hip_sync(ctx) != DBDE_HIP_OK) return 0;
+    return (size_t)nbytes;
+}
+
+size_t dbde_hip_pack_frame(dbde_hip_ctx *ctx, uint64_t index, const uint8_t *image, int W, int H, uint8_t *target) {
+    size_t n = encode_one_host(ctx, index, image, W, H);
+    if (!n || !target) return 0;
+    if (hipMemcpy(target, ctx->st_pack, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+size_t dbde_hip_pack_image(dbde_hip_ctx *ctx, const uint8_t *image, int W, int H, uint8_t *target) {
+    size_t n = encode_one_host(ctx, 0, image, W, H);
+    if (n <= 20 || !target) return 0;
+    if (hipMemcpy(target, ctx->st_pack + 20, n - 20, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n - 20;
+}
+
+uint32_t dbde_hip_pack_8x8_partial(dbde_hip_ctx *ctx, const uint8_t *image, int stride, int rightmargin,
+                                   int downmargin, uint8_t *target) {
+    // A rm x dm image is exactly one constant-padded tile (dbde_util.cpp:105-135).
+    if (!ctx || !image || rightmargin < 1 || downmargin < 1) return 0;
+    const int rm = rightmargin > 8 ? 8 : rightmargin, dm = downmargin > 8 ? 8 : downmargin;
+    uint8_t dense[64];
+    for (int r = 0; r < dm; r++) memcpy(dense + r * rm, image + (ptrdiff_t)r * stride, (size_t)rm);   // gather only
+    size_t n = encode_one_host(ctx, 0, dense, rm, dm);
+    if (n < 34) return 0;
+    uint8_t head[34 + 64];
+    if (hipMemcpy(head, ctx->st_pack, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    // T = 1: header 20 | nb 4 | depth 1 | nm 4 | min 1 | n64 4 | payload
+    const uint32_t depth = head[24], mn = head[29];
+    if (target && depth) memcpy(target, head + 34, 8u * depth);
+    return (depth << 8) | mn;
+}
+
+uint32_t dbde_hip_pack_8x8(dbde_hip_ctx *ctx, const uint8_t *image, int stride, uint8_t *target) {
+    return dbde_hip_pack_8x8_partial(ctx, image, stride, 8, 8, target);
+}
+
+// Runs index + decode for one frame_data already resident at ctx->st_pack + 20 (a dummy
+// frame header precedes it).  Returns bytes of frame data consumed (0 = rejected) and leaves
+// the image in ctx->st_img.
+static size_t decode_one_staged(dbde_hip_ctx *ctx, size_t staged_bytes, int W, int H, bool prefill,
+                                const uint8_t *image_in) {
+    Geometry g;
+    if (!geometry(W, H, g)) return 0;
+    uint64_t *d_off = ctx->scratch64 + 2;
+    const uint64_t zero = 0;
+    if (hipMemcpyAsync(d_off, &zero, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
+    (void)prefill;
+    (void)image_in;
+    dbde_hip_frame_result *d_res = reinterpret_cast<dbde_hip_frame_result *>(ctx->st_pack + ((staged_bytes + 63) & ~(size_t)63));
+    if (dbde_hip_decode_frames(ctx, ctx->st_pack, staged_bytes, d_off, W, H, 1, ctx->st_img, d_res) != DBDE_HIP_OK) return 0;
+    dbde_hip_frame_result res;
+    if (hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0;
+    if (dbde_hip_sync(ctx) != DBDE_HIP_OK) return 0;
+    return res.consumed > 20 ? (size_t)(res.consumed - 20) : 0;
+}
+
+size_t dbde_hip_unpack_image(dbde_hip_ctx *ctx, const uint8_t *packed, int W, int H, uint8_t *image) {
+    Geometry g;
+    if (!ctx || !packed || !image || !geometry(W, H, g)) return 0;
+    // Only to learn how many bytes to move: the first I32 and the word count
+    // (validation proper happens on the device, dbde_util.cpp:295-303 order preserved).
+    if ((int32_t)get32(packed) != (int32_t)g.T) return 0;
+    if ((int32_t)get32(packed + 4 + g.T) != (int32_t)g.T) return 0;
+    const int32_t n64 = (int32_t)get32(packed + 8 + 2 * (size_t)g.T);
+    if (n64 < 0 || (uint64_t)n64 > 8ull * g.T) return 0;   // cannot equal sum(depth) with depth <= 8
+    const size_t body = 12 + 2 * (size_t)g.T + 8 * (size_t)n64;
+    if (ensure_staging(ctx, (size_t)g.pixels, 20 + body + 128)) return 0;
+    uint8_t hdr[20];
+    dbde_hip_frame_header fh = {2, 0, 0};
+    dbde_hip_pack_frame_header(&fh, hdr);
+    if (hipMemcpyAsync(ctx->st_pack, hdr, 20, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
+    if (hipMemcpyAsync(ctx->st_pack + 20, packed, body, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
+    const size_t used = decode_one_staged(ctx, 20 + body, W, H, false, nullptr);
+    if (!used) return 0;
+    if (hipMemcpy(image, ctx->st_img, (size_t)g.pixels, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return used;
+}
+
+dbde_hip_frame_header dbde_hip_unpack_frame(dbde_hip_ctx *ctx, uint8_t **packed, int W, int H, uint8_t *image) {
+    dbde_hip_frame_header fh = dbde_hip_unpack_frame_header(packed);   // advances by 20 (dbde_util.cpp:340)
+    const size_t n = dbde_hip_unpack_image(ctx, *packed, W, H, image);
+    if (n == 0) fh.u64s = 0xFFFFFFFFu;   // dbde_util.cpp:342
+    else *packed += n;
+    return fh;
+}
+
+void dbde_hip_unpack_8x8_partial(dbde_hip_ctx *ctx, uint8_t depth, uint8_t minval, const uint8_t *packed,
+                                 size_t stride, int rightmargin, int downmargin, uint8_t *image) {
+    if (!ctx || !image || depth > 8 || rightmargin < 1 || downmargin < 1) return;
+    const int rm = rightmargin > 8 ? 8 : rightmargin, dm = downmargin > 8 ? 8 : downmargin;
+    // frame data of a one-tile rm x dm frame
+    uint8_t body[14 + 64];
+    put32(body, 1);
+    body[4] = depth;
+    put32(body + 5, 1);
+    body[9] = minval;
+    put32(body + 10, depth);
+    if (depth) memcpy(body + 14, packed, 8u * depth);
+    uint8_t dense[64];
+    if (dbde_hip_unpack_image(ctx, body, rm, dm, dense) == 0) return;
+    for (int r = 0; r < dm; r++) memcpy(image + r * stride, dense + r * rm, (size_t)rm);   // scatter only
+}
+
+void dbde_hip_unpack_8x8(dbde_hip_ctx *ctx, uint8_t depth, uint8_t minval, const uint8_t *packed, size_t stride,
+                         uint8_t *image) {
+    dbde_hip_unpack_8x8_partial(ctx, depth, minval, packed, stride, 8, 8, image);
+}
+
+// ---- header wire format ----------------------------------------------------------------------
+
+size_t dbde_hip_pack_frame_header(const dbde_hip_frame_header *fh, uint8_t *target) {
+    put32(target, fh->u64s);
+    put64(target + 4, fh->index);
+    const double el = (double)fh->elapsed_ns;   // the reference stores a double here (dbde_util.cpp:186)
+    uint64_t bits;
+    memcpy(&bits, &el, 8);
+    put64(target + 12, bits);
+    return 20;
+}
+
+size_t dbde_hip_pack_video_header(const dbde_hip_video_header *vh, uint8_t *target) {
+    put32(target, vh->u64s);
+    put64(target + 4, vh->height);
+    put64(target + 12, vh->width);
+    uint64_t bits;
+    memcpy(&bits, &vh->frame_hz, 8);
+    put64(target + 20, bits);
+    return 28;
+}
+
+dbde_hip_frame_header dbde_hip_unpack_frame_header(uint8_t **packed) {
+    dbde_hip_frame_header fh;
+    const uint8_t *p = *packed;
+    fh.u64s = get32(p);
+    fh.index = get64(p + 4);
+    const uint64_t bits = get64(p + 12);
+    double el;
+    memcpy(&el, &bits, 8);
+    fh.elapsed_ns = (uint64_t)el;
+    if (fh.u64s != 2) fh.u64s = 0xFFFFFFFFu;
+    *packed += 20;
+    return fh;
+}
+
+dbde_hip_video_header dbde_hip_unpack_video_header(uint8_t **packed) {
+    dbde_hip_video_header vh;
+    const uint8_t *p = *packed;
+    vh.u64s = get32(p);
+    vh.height = get64(p + 4);
+    vh.width = get64(p + 12);
+    const uint64_t bits = get64(p + 20);
+    memcpy(&vh.frame_hz, &bits, 8);
+    if (vh.u64s != 3) vh.u64s = 0xFFFFFFFFu;
+    *packed += 28;
+    return vh;
+}
+
+// ---- timing ----------------------------------------------------------------------------------
+
+int dbde_hip_timing_enable(dbde_hip_ctx *ctx, int on) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    ctx->timing = on != 0;
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[3], uint64_t launches[3], int reset) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->spans) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
+            ctx->acc_ms[s.kind] += t;
+            ctx->acc_n[s.kind] += 1;
+        }
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    ctx->spans.clear();
+    for (int k = 0; k < 3; k++) {
+        if (ms) ms[k] = ctx->acc_ms[k];
+        if (launches) launches[k] = ctx->acc_n[k];
+        if (reset) { ctx->acc_ms[k] = 0; ctx->acc_n[k] = 0; }
+    }
+    return DBDE_HIP_OK;
+}
+
+}  // extern "C"

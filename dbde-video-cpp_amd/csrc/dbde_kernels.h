@@ -1,0 +1,81 @@
+// dbde_kernels.h -- launch interface between the C-ABI (dbde_capi.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dbde {
+
+// A chunk is the unit of one 256-thread workgroup: 512 consecutive tiles in stream order
+// (row-major over the frame's tiles), two tiles per lane.
+constexpr int kBlockThreads = 256;
+constexpr uint32_t kChunkTiles = 512;
+constexpr uint32_t kMaxChunkWords = kChunkTiles * 8;   // U64 words of payload per chunk, worst case
+
+// Decoupled look-back record, one per chunk, 64 bits, written and read with relaxed
+// agent-scope atomics (the record IS the flag, so no fence is needed):
+//   [63:62] status  0 = not yet, 1 = AGG (chunk total only), 2 = INC (inclusive prefixes), 3 = POISON
+//   AGG : [31:0]  payload words of this chunk
+//   INC : [61:32] payload words of this frame up to and including this chunk (< 2^30)
+//         [31:0]  payload words of the whole launch up to and including this chunk (mod 2^32)
+constexpr unsigned long long kStAgg = 1ull << 62, kStInc = 2ull << 62, kStPoison = 3ull << 62;
+
+struct EncParams {
+    const uint8_t *images;         // n_frames * W*H
+    uint8_t *out;
+    uint64_t *frame_offsets;       // optional [n_frames]
+    uint64_t *frame_bytes;         // optional [n_frames]
+    const uint64_t *indices;       // optional [n_frames]
+    const uint64_t *elapsed_ns;    // optional [n_frames]
+    uint64_t first_index;
+    unsigned long long *state;     // [n_chunks] look-back records, zeroed before the launch
+    uint32_t *ctrl;                // [0] ticket counter; zeroed before the launch
+    uint32_t *sticky;              // context-wide failure word, OR-ed on look-back time-out
+    uint64_t slot_stride;          // 0 = frames concatenated
+    uint64_t frame_pixels;         // W*H
+    int W, H;
+    uint32_t w, h, T;              // tiles across, down, total
+    uint32_t chunks_per_frame, n_chunks;
+};
+
+struct DecParams {
+    const uint8_t *stream;
+    const uint64_t *frame_offsets;  // [n_frames] byte offset of each frame header
+    uint8_t *images;
+    const uint32_t *chunk_off;      // [n_chunks] payload word offset of each chunk inside its frame
+    const uint32_t *frame_ok;       // [n_frames] 1 = frame data validated
+    uint64_t frame_pixels;
+    int W, H;
+    uint32_t w, h, T;
+    uint32_t chunks_per_frame, n_chunks;
+};
+
+struct IdxParams {
+    const uint8_t *stream;
+    const uint64_t *frame_offsets;
+    uint64_t stream_bytes;
+    uint32_t *chunk_off;            // out [n_frames * chunks_per_frame]
+    uint32_t *frame_ok;             // out [n_frames]
+    void *results;                  // optional dbde_hip_frame_result[n_frames]
+    uint32_t T, chunks_per_frame;
+};
+
+struct FrameResultDev {             // layout of dbde_hip_frame_result
+    uint32_t u64s;
+    uint32_t pad_;
+    uint64_t index;
+    uint64_t elapsed_ns;
+    uint64_t consumed;
+};
+
+hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
+hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
+hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s);
+hipError_t launch_synth(int mode, uint64_t seed, uint64_t first_frame, int n_frames, int W, int H,
+                        uint8_t *d_images, hipStream_t s);
+// Serial frame-to-frame hop over a concatenated stream (one wave); see dbde_hip_index_stream.
+hipError_t launch_scan_stream(const uint8_t *stream, uint64_t stream_bytes, uint32_t T, int max_frames,
+                              uint64_t *d_offsets, uint32_t *d_count, hipStream_t s);
+// Maximum chunks_per_frame the decode index kernel can hold in LDS.
+constexpr uint32_t kMaxChunksPerFrame = 32768;
+
+}  // namespace dbde

@@ -1,0 +1,177 @@
+/*
+ * dbde_hip.h -- C-ABI of the MI355X (gfx950) DBDE frame codec: libdbde_hip.so.
+ *
+ * This is the drop-in boundary for the reference's hot path, dbde_util.h:21-37
+ * (dbde_pack_* / dbde_unpack_*).  Plain C: pointers, sizes and fixed-width integers only.
+ * Two layers live behind it:
+ *
+ *   1. the batch API on DEVICE-RESIDENT buffers (dbde_hip_encode_frames /
+ *      dbde_hip_decode_frames): N frames per launch, what bench.py measures;
+ *   2. host-pointer entry points with the argument meaning of the reference functions they
+ *      replace (each cites its reference line); include/dbde_util.h re-exports them under
+ *      the reference's own C++ names, so code written against the reference links unchanged.
+ *
+ * All compute runs in hand-written HIP kernels (csrc/dbde_kernels.hip).  There is no CPU
+ * fallback: every entry point fails with DBDE_HIP_ERR_HIP when no gfx950 device is usable.
+ *
+ * Wire format (all little-endian; reference README.md:12-67, dbde_util.cpp:137-209):
+ *   stream := video_header(28 B) { frame_header(20 B) frame_data }*
+ *   frame_data := I32 T | U8 depth[T] | I32 T | U8 min[T] | I32 n64 | U64 data[n64]
+ *   T = ceil(W/8)*ceil(H/8) 8x8 tiles, row-major; n64 = sum(depth)
+ */
+#ifndef DBDE_HIP_H
+#define DBDE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dbde_hip_ctx dbde_hip_ctx;
+
+enum {
+    DBDE_HIP_OK = 0,
+    DBDE_HIP_ERR_ARG = -1,       /* bad argument (null pointer, W/H out of range, ...) */
+    DBDE_HIP_ERR_HIP = -2,       /* HIP runtime error or no usable gfx950 device */
+    DBDE_HIP_ERR_CAPACITY = -3,  /* output buffer smaller than the worst case */
+    DBDE_HIP_ERR_DEVICE = -4     /* a kernel reported failure (look-back time-out) */
+};
+
+/* In-memory headers, field-for-field the reference's structs (dbde_util.h:8-19). */
+typedef struct {
+    uint32_t u64s;
+    uint64_t height;
+    uint64_t width;
+    double frame_hz;
+} dbde_hip_video_header;
+
+typedef struct {
+    uint32_t u64s;       /* 2, or 0xFFFFFFFF when the frame failed to parse (dbde_util.cpp:335,342) */
+    uint64_t index;
+    uint64_t elapsed_ns;
+} dbde_hip_frame_header;
+
+/* Per-frame result of a batch decode (device memory, one per frame). */
+typedef struct {
+    dbde_hip_frame_header header;  /* as dbde_unpack_frame would return it */
+    uint64_t consumed;             /* bytes the reference would advance *packed by (20 on failure) */
+} dbde_hip_frame_result;
+
+/* ---- context -------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device`.  `stream` is a hipStream_t (or NULL for the
+ * default stream) on which every kernel and copy of this context is enqueued; the caller
+ * keeps ownership of it.  Workspace (look-back state, decode index, staging buffers for the
+ * host-pointer entry points) is owned by the context and grown on demand. */
+int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out);
+void dbde_hip_destroy(dbde_hip_ctx *ctx);
+/* Blocks until everything enqueued by this context has finished; returns
+ * DBDE_HIP_ERR_DEVICE if a kernel raised its failure flag since the last call. */
+int dbde_hip_sync(dbde_hip_ctx *ctx);
+const char *dbde_hip_last_error(const dbde_hip_ctx *ctx);
+/* Name of the device the context runs on (e.g. "gfx950:sramecc+:xnack-"). */
+const char *dbde_hip_device_arch(const dbde_hip_ctx *ctx);
+
+/* ---- sizes ---------------------------------------------------------------------------- */
+
+/* Worst-case bytes of one packed frame incl. its 20-byte header: 20 + 12 + 66*T
+ * (the bound the reference's test allocates, dbde_util_test.cpp:78). */
+size_t dbde_hip_max_frame_bytes(int W, int H);
+/* Exact bytes of frame_data for a frame with n64 payload words: 12 + 2T + 8*n64. */
+size_t dbde_hip_image_bytes(int W, int H, uint64_t n64);
+
+/* ---- batch API, device pointers (the measured path) ----------------------------------- */
+
+/* Encodes n_frames images (contiguous, W*H bytes each, row-major U8, pitch W) into DBDE
+ * frames (frame header + frame data each), replacing n_frames calls of dbde_pack_frame
+ * (dbde_util.cpp:190-196).
+ *   d_indices    : optional frame numbers (device, n_frames); NULL -> first_index + f
+ *   d_elapsed_ns : optional elapsed_ns per frame (device); NULL -> 0 as dbde_pack_frame writes
+ *   d_out        : output bytes (device), capacity out_capacity
+ *   slot_stride  : 0 -> frames are CONCATENATED from d_out (a ready-to-write .dbde body);
+ *                  else frame f starts at d_out + f*slot_stride (>= dbde_hip_max_frame_bytes)
+ *   d_frame_offsets / d_frame_bytes : optional outputs (device, n_frames each): byte offset of
+ *                  each frame from d_out and its exact length.
+ * Asynchronous on the context's stream.  out_capacity must cover the worst case
+ * (n_frames * dbde_hip_max_frame_bytes, or (n_frames-1)*slot_stride + max). */
+int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, int H, int n_frames,
+                           uint64_t first_index, const uint64_t *d_indices,
+                           const uint64_t *d_elapsed_ns, uint8_t *d_out, size_t out_capacity,
+                           uint64_t slot_stride, uint64_t *d_frame_offsets,
+                           uint64_t *d_frame_bytes);
+
+/* Decodes n_frames frames, replacing n_frames calls of dbde_unpack_frame
+ * (dbde_util.cpp:339-345).  Frame f starts at d_stream + d_frame_offsets[f] (any byte
+ * alignment).  stream_bytes is the readable extent of d_stream.  A frame whose frame data
+ * fails validation (nb != T, nm != T, n64 != sum(depth): dbde_util.cpp:295-303; or a depth
+ * byte > 8, the one documented deviation) leaves its image untouched and reports
+ * header.u64s = 0xFFFFFFFF, consumed = 20.  d_results may be NULL. */
+int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes,
+                           const uint64_t *d_frame_offsets, int W, int H, int n_frames,
+                           uint8_t *d_images, dbde_hip_frame_result *d_results);
+
+/* Builds the frame index of a concatenated frame sequence starting at d_stream (no video
+ * header): hops 20 + 12 + 2T + 8*n64 from frame to frame (README.md:12-23) until max_frames
+ * or the end of stream_bytes.  Writes offsets (device, max_frames) and returns the number of
+ * whole frames found in *n_found (host).  Synchronous. */
+int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W,
+                          int H, int max_frames, uint64_t *d_frame_offsets, int *n_found);
+
+/* Counter-based synthetic frames (same bytes as oracle/synth.c): mode 0 noise8, 1 mixed,
+ * 2 flat, 3 smooth.  Used by bench.py and the parity tests to build inputs in HBM. */
+int dbde_hip_synth_frames(dbde_hip_ctx *ctx, int mode, uint64_t seed, uint64_t first_frame,
+                          int n_frames, int W, int H, uint8_t *d_images);
+
+/* ---- host-pointer entry points: the reference signatures, on the GPU -------------------- */
+/* Each copies its operands to the device, runs the same kernels as the batch API, copies
+ * the result back and synchronises.  Return values and written bytes are the reference's. */
+
+/* dbde_pack_8x8 (dbde_util.h:21, dbde_util.cpp:22-103): returns (depth<<8)|min, writes
+ * exactly 8*depth bytes at target. */
+uint32_t dbde_hip_pack_8x8(dbde_hip_ctx *ctx, const uint8_t *image, int stride, uint8_t *target);
+/* dbde_pack_8x8_partial (dbde_util.h:22, dbde_util.cpp:105-135). */
+uint32_t dbde_hip_pack_8x8_partial(dbde_hip_ctx *ctx, const uint8_t *image, int stride,
+                                   int rightmargin, int downmargin, uint8_t *target);
+/* dbde_pack_image (dbde_util.h:24, dbde_util.cpp:137-180): returns 12 + 2T + 8*n64. */
+size_t dbde_hip_pack_image(dbde_hip_ctx *ctx, const uint8_t *image, int W, int H, uint8_t *target);
+/* dbde_pack_frame (dbde_util.h:26, dbde_util.cpp:190-196). */
+size_t dbde_hip_pack_frame(dbde_hip_ctx *ctx, uint64_t index, const uint8_t *image, int W, int H,
+                           uint8_t *target);
+/* dbde_unpack_8x8 (dbde_util.h:30, dbde_util.cpp:216-279); depth > 8 is ignored (no write). */
+void dbde_hip_unpack_8x8(dbde_hip_ctx *ctx, uint8_t depth, uint8_t minval, const uint8_t *packed,
+                         size_t stride, uint8_t *image);
+/* dbde_unpack_8x8_partial (dbde_util.h:31, dbde_util.cpp:281-289). */
+void dbde_hip_unpack_8x8_partial(dbde_hip_ctx *ctx, uint8_t depth, uint8_t minval,
+                                 const uint8_t *packed, size_t stride, int rightmargin,
+                                 int downmargin, uint8_t *image);
+/* dbde_unpack_image (dbde_util.h:33, dbde_util.cpp:291-328): bytes consumed, 0 on failure. */
+size_t dbde_hip_unpack_image(dbde_hip_ctx *ctx, const uint8_t *packed, int W, int H,
+                             uint8_t *image);
+/* dbde_unpack_frame (dbde_util.h:35, dbde_util.cpp:339-345): *packed is advanced exactly as
+ * the reference advances it (by 20 only when the frame data is rejected). */
+dbde_hip_frame_header dbde_hip_unpack_frame(dbde_hip_ctx *ctx, uint8_t **packed, int W, int H,
+                                            uint8_t *image);
+
+/* ---- header wire format (host only; a few bytes, no kernel) ----------------------------- */
+/* dbde_pack_frame_header (dbde_util.cpp:182-188): 20 bytes; elapsed_ns travels as an F64. */
+size_t dbde_hip_pack_frame_header(const dbde_hip_frame_header *fh, uint8_t *target);
+/* dbde_pack_video_header (dbde_util.cpp:198-209): 28 bytes, height before width. */
+size_t dbde_hip_pack_video_header(const dbde_hip_video_header *vh, uint8_t *target);
+/* dbde_unpack_frame_header (dbde_util.cpp:330-337): advances *packed by 20. */
+dbde_hip_frame_header dbde_hip_unpack_frame_header(uint8_t **packed);
+/* dbde_unpack_video_header (dbde_util.cpp:347-359): advances *packed by 28. */
+dbde_hip_video_header dbde_hip_unpack_video_header(uint8_t **packed);
+
+/* ---- kernel timing hook for bench.py ---------------------------------------------------- */
+/* When enabled, every encode / decode call brackets its kernels with HIP events on the
+ * context's stream; dbde_hip_timing_read returns accumulated milliseconds and launch counts
+ * ([0]=encode kernel, [1]=decode index kernel, [2]=decode kernel) after synchronising. */
+int dbde_hip_timing_enable(dbde_hip_ctx *ctx, int on);
+int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[3], uint64_t launches[3], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,274 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle and the golden fixtures.
+
+Everything here calls libdbde_hip.so; the oracle is only the checker.  Bit-exact is the bar:
+this is byte and integer work, there is no tolerance anywhere in this file.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"noise8": 0, "mixed": 1, "flat": 2, "smooth": 3}
+SEED = 0xDBDE2016
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def dv():
+    import dbde_video_cpp_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def codec(dv):
+    c = dv.Codec(0)
+    assert c.arch.startswith("gfx950")
+    yield c
+    c.close()
+
+
+def gpu_encode(codec, imgs, W, H, n, first_index=0, slot_stride=0, misalign=0, **kw):
+    """-> list of per-frame packed byte arrays (host)."""
+    import torch
+    buf, lead, cap = codec.alloc_stream(W, H, n, slot_stride=slot_stride, lead=32 + 16)
+    lead += misalign
+    buf.fill_(0xEE)
+    offs, sizes = codec.encode_frames(imgs, W, H, n, buf, lead, cap, first_index=first_index,
+                                      slot_stride=slot_stride, **kw)
+    codec.sync()
+    host = buf.cpu().numpy()
+    o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+    frames = [host[lead + o[f]: lead + o[f] + s[f]].copy() for f in range(n)]
+    # nothing outside the frames may be touched
+    mask = np.ones(len(host), bool)
+    for f in range(n):
+        mask[lead + o[f]: lead + o[f] + s[f]] = False
+    assert (host[mask] == 0xEE).all(), "encoder wrote outside the frames it reported"
+    if not slot_stride:
+        assert o[0] == 0 and all(o[f + 1] == o[f] + s[f] for f in range(n - 1)), "frames not concatenated"
+    else:
+        assert all(o[f] == f * slot_stride for f in range(n))
+    return frames, (buf, lead, offs, sizes)
+
+
+def test_synth_matches_oracle(codec, oracle):
+    for (W, H) in [(10, 10), (64, 64), (200, 123), (1921, 9)]:
+        for mname, mode in MODES.items():
+            got = codec.synth_frames(mname, SEED, 5, 3, W, H).cpu().numpy()
+            for f in range(3):
+                assert (got[f] == oracle.synth_frame(mode, SEED, 5 + f, W, H)).all(), (W, H, mname, f)
+
+
+def test_golden_frames_host_api(codec, golden):
+    """dbde_pack_frame / dbde_unpack_frame semantics on every fixture the reference produced."""
+    manifest, arrays = golden
+    for e in manifest["frames"]:
+        img, want = arrays[e["name"] + ".image"], arrays[e["name"] + ".packed"]
+        got = codec.pack_frame(e["index"], img, e["W"], e["H"])
+        assert got.tobytes() == want.tobytes(), e["name"]
+        body = codec.pack_image(img, e["W"], e["H"])
+        assert body.tobytes() == want[20:].tobytes(), e["name"]
+        n, fh, back = codec.unpack_frame(want, e["W"], e["H"])
+        assert n == len(want) and fh == (2, e["index"], 0) and (back == img).all(), e["name"]
+        n, back = codec.unpack_image(want[20:], e["W"], e["H"])
+        assert n == len(want) - 20 and (back == img).all(), e["name"]
+
+
+def test_reference_known_answer_stream(codec, dv, golden):
+    """The reference's own KAT (dbde_util_test.cpp:135-213), replayed through the HIP path."""
+    from test_oracle_golden import KAT_STREAM
+    _, arrays = golden
+    img = arrays["kat_8x16.image"]
+    stream = np.frombuffer(KAT_STREAM, np.uint8)
+    n, vh = dv.unpack_video_header(stream)
+    assert n == 28 and vh == (3, 8, 16, 1.0)
+    n, fh = dv.unpack_frame_header(stream[28:])
+    assert n == 20 and fh == (2, 1, 0)
+    n, fh, back = codec.unpack_frame(stream[28:], 16, 8)
+    assert n == 100 and fh == (2, 1, 0) and (back == img).all()
+    out = np.concatenate([dv.pack_video_header(3, 8, 16, 1.0), codec.pack_frame(1, img, 16, 8)])
+    assert out.tobytes() == KAT_STREAM
+
+
+def test_tile_api(codec, oracle, golden):
+    manifest, arrays = golden
+    flat = arrays["demo_10x10.image"].reshape(-1).copy()
+    for t in manifest["tile_demos"]:
+        if t["rm"] == 8 and t["dm"] == 8:
+            code, payload, raw = codec.pack_8x8(flat, t["off"], 10)
+        else:
+            code, payload, raw = codec.pack_8x8_partial(flat, t["off"], 10, t["rm"], t["dm"])
+        assert code == t["code"] and payload.tobytes().hex() == t["payload"]
+        assert (raw[len(payload):] == 0xEE).all()
+        canvas = np.full(100, 0xEE, np.uint8)
+        codec.unpack_8x8_partial(code >> 8, code & 0xFF, payload, 10, t["rm"], t["dm"], canvas, 0)
+        want = np.full(100, 0xEE, np.uint8)
+        oracle.unpack_8x8_partial(code >> 8, code & 0xFF, payload, 10, t["rm"], t["dm"], want, 0)
+        assert (canvas == want).all()
+    for rng, depth in manifest["depth_bounds"]:
+        tile = np.zeros(64, np.uint8)
+        tile[5] = rng
+        code, payload, _ = codec.pack_8x8(tile, 0, 8)
+        assert code >> 8 == depth and len(payload) == 8 * depth
+    # random tiles at a stride, every depth
+    rng = np.random.default_rng(7)
+    for d in range(9):
+        img = (rng.integers(0, 256 - (1 << d) + 1) + rng.integers(0, 1 << d, (8, 24))).astype(np.uint8).reshape(-1)
+        code, payload, _ = codec.pack_8x8(img, 8, 24)
+        wcode, wpayload, _ = oracle.pack_8x8(img, 8, 24)
+        assert code == wcode and payload.tobytes() == wpayload.tobytes()
+        canvas = np.full(8 * 24 + 8, 0xEE, np.uint8)
+        codec.unpack_8x8(code >> 8, code & 0xFF, payload, 24, canvas, 8)
+        want = np.full(8 * 24 + 8, 0xEE, np.uint8)
+        oracle.unpack_8x8(code >> 8, code & 0xFF, payload, 24, want, 8)
+        assert (canvas == want).all()
+
+
+@pytest.mark.parametrize("W,H,n", [(10, 10, 3), (16, 8, 2), (64, 64, 4), (200, 123, 5), (1024, 40, 3),
+                                   (4096, 24, 2), (4104, 16, 2), (8200, 9, 2), (33, 31, 7), (1, 1, 4), (7, 300, 2)])
+@pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
+def test_batch_encode_matches_oracle(codec, oracle, W, H, n, mode):
+    import torch
+    imgs = codec.synth_frames(mode, SEED, 100, n, W, H)
+    imgs_h = imgs.cpu().numpy()
+    for slot in (0, ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256):
+        for misalign in (0, 3):
+            frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=100,
+                                                          slot_stride=slot, misalign=misalign)
+            for f in range(n):
+                want = oracle.pack_frame(100 + f, imgs_h[f], W, H)
+                assert frames[f].tobytes() == want.tobytes(), (W, H, mode, slot, misalign, f)
+            total = int((offs[-1] + sizes[-1]).item())
+            back, res = codec.decode_frames(buf, lead, total, offs, W, H, n)
+            codec.sync()
+            assert torch.equal(back, imgs), (W, H, mode, slot, misalign)
+            for f, r in enumerate(codec.parse_results(res)):
+                assert r == (2, 100 + f, 0, len(frames[f]))
+
+
+def test_indices_and_elapsed(codec, oracle, golden):
+    import torch
+    manifest, _ = golden
+    W, H, n = 40, 24, 6
+    cases = [h["in"] for h in manifest["headers"]["frame"] if h["in"][0] == 2]
+    n = len(cases)
+    imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+    idx = torch.from_numpy(np.array([c[1] for c in cases], np.uint64).view(np.int64)).to(imgs.device)
+    el = torch.from_numpy(np.array([c[2] for c in cases], np.uint64).view(np.int64)).to(imgs.device)
+    frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, indices=idx, elapsed_ns=el)
+    wires = {tuple(h["in"]): h for h in manifest["headers"]["frame"]}
+    for f, c in enumerate(cases):
+        assert frames[f][:20].tobytes().hex() == wires[tuple(c)]["wire"]
+    total = int((offs[-1] + sizes[-1]).item())
+    _, res = codec.decode_frames(buf, lead, total, offs, W, H, n)
+    codec.sync()
+    for f, r in enumerate(codec.parse_results(res)):
+        assert list(r[:3]) == wires[tuple(cases[f])]["out"]
+
+
+def test_malformed_frames(codec, oracle, golden):
+    import torch
+    manifest, arrays = golden
+    base = arrays["malformed_base.packed"]
+    for m in manifest["malformed"]:
+        bad = base.copy()
+        bad[m["pos"]] = (int(bad[m["pos"]]) + m["delta"]) % 256
+        n, fh, img = codec.unpack_frame(bad, 10, 10, fill=0xEE)
+        assert n == m["advance"] and fh[0] == m["u64s"] and fh[1] == m["index"], m["label"]
+        assert bool((img == 0xEE).all()) == m["image_untouched"] and sha(img) == m["image_sha"], m["label"]
+        n_img, _ = codec.unpack_image(bad[20:], 10, 10)
+        assert n_img == m["unpack_image_ret"], m["label"]
+    # depth byte > 8: rejected (the documented deviation), image untouched
+    bad = base.copy()
+    bad[24] = 9
+    bad[36] = (int(bad[36]) + 5) % 256
+    n, fh, img = codec.unpack_frame(bad, 10, 10, fill=0xEE)
+    assert n == 20 and fh[0] == 0xFFFFFFFF and (img == 0xEE).all()
+    # batch: one bad frame among good ones leaves only its own image untouched
+    W, H, n = 72, 40, 5
+    imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+    frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n)
+    o = offs.cpu().numpy()
+    T = ((W + 7) // 8) * ((H + 7) // 8)
+    buf[lead + int(o[2]) + 28 + 2 * T] += 1          # corrupt n64 of frame 2
+    total = int((offs[-1] + sizes[-1]).item())
+    canvas = torch.full((n, H, W), 0xEE, dtype=torch.uint8, device=imgs.device)
+    back, res = codec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
+    codec.sync()
+    r = codec.parse_results(res)
+    for f in range(n):
+        if f == 2:
+            assert r[f][0] == 0xFFFFFFFF and r[f][3] == 20 and bool((back[f] == 0xEE).all())
+        else:
+            assert r[f][0] == 2 and torch.equal(back[f], imgs[f])
+    # byte-wise wrapping add on decode: min + value > 255 in a stream that passes validation
+    img = np.zeros((8, 8), np.uint8)
+    img[0, 1] = 255
+    packed = oracle.pack_frame(0, img, 8, 8)
+    packed[20 + 4 + 1 + 4] = 200
+    n1, f1, i1 = codec.unpack_frame(packed, 8, 8)
+    n2, f2, i2 = oracle.unpack_frame(packed, 8, 8)
+    assert n1 == n2 and f1 == f2 and (i1 == i2).all()
+
+
+def test_index_stream(codec):
+    W, H, n = 200, 123, 9
+    imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+    frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n)
+    total = int((offs[-1] + sizes[-1]).item())
+    found, cnt = codec.index_stream(buf, lead, total, W, H, 100)
+    assert cnt == n and (found.cpu().numpy() == offs.cpu().numpy()).all()
+    found, cnt = codec.index_stream(buf, lead, total - 1, W, H, 100)   # truncated last frame
+    assert cnt == n - 1
+
+
+@pytest.mark.parametrize("name", ["cfg2_4096x3072", "cfg3_2048x2048", "cfg4_1921x1081"])
+def test_baseline_configs_full_size(codec, golden, name):
+    """BASELINE.json configs 2-4: packed-frame hashes equal the REAL reference's (fixtures)."""
+    import torch
+    manifest, _ = golden
+    for e in [e for e in manifest["big"] if e["name"] == name]:
+        W, H = e["W"], e["H"]
+        imgs = codec.synth_frames(e["mode"], manifest["seed"], e["frame"], 1, W, H)
+        assert sha(imgs.cpu().numpy()) == e["image_sha"]
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, 1, first_index=e["frame"])
+        assert len(frames[0]) == e["packed_bytes"] and sha(frames[0]) == e["packed_sha"], e
+        back, res = codec.decode_frames(buf, lead, len(frames[0]), offs, W, H, 1)
+        codec.sync()
+        assert torch.equal(back, imgs)
+
+
+def test_large_batch_properties(codec, oracle):
+    """Size-independent checks at bench scale: 48 distinct 4096x3072 frames (604 MB raw,
+    beyond the 256 MiB Infinity Cache): concatenation, exact sizes, round trip, and three
+    frames spot-checked byte-for-byte against the oracle."""
+    import torch
+    W, H, n = 4096, 3072, 48
+    T = (W // 8) * (H // 8)
+    for mode in ("mixed", "noise8"):
+        imgs = codec.synth_frames(mode, SEED, 0, n, W, H)
+        buf, lead, cap = codec.alloc_stream(W, H, n)
+        offs, sizes = codec.encode_frames(imgs, W, H, n, buf, lead, cap)
+        codec.sync()
+        o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+        assert o[0] == 0 and (o[1:] == np.cumsum(s)[:-1]).all()
+        host = buf.cpu().numpy()
+        for f in range(n):
+            fr = host[lead + o[f]: lead + o[f] + s[f]]
+            n64 = int(fr[28 + 2 * T: 32 + 2 * T].view("<u4")[0])
+            assert s[f] == 32 + 2 * T + 8 * n64 and n64 == int(fr[24:24 + T].astype(np.int64).sum())
+            if mode == "noise8":
+                assert n64 == 8 * T
+        for f in (0, 17, n - 1):
+            want = oracle.pack_frame(f, oracle.synth_frame(MODES[mode], SEED, f, W, H), W, H)
+            assert host[lead + o[f]: lead + o[f] + s[f]].tobytes() == want.tobytes(), (mode, f)
+        back, res = codec.decode_frames(buf, lead, int(o[-1] + s[-1]), offs, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs)
+        assert all(r == (2, f, 0, int(s[f])) for f, r in enumerate(codec.parse_results(res)))
+        del imgs, buf, back

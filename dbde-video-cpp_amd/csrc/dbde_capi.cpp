@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,7 @@ struct dbde_hip_ctx {
     uint8_t *st_pack = nullptr;
     size_t st_pack_bytes = 0;
     // timing
+    uint32_t exp_flags = 0;          // $DBDE_HIP_EXPERIMENT (tuning experiments only)
     bool timing = false;
     std::vector<TimedSpan> spans;
     double acc_ms[3] = {0, 0, 0};
@@ -113,12 +115,12 @@ void span_begin(dbde_hip_ctx *ctx, int kind) {
     TimedSpan s;
     s.kind = kind;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
-    hipEventRecord(s.a, ctx->stream);
+    (void)hipEventRecord(s.a, ctx->stream);
     ctx->spans.push_back(s);
 }
 void span_end(dbde_hip_ctx *ctx) {
     if (!ctx->timing || ctx->spans.empty()) return;
-    hipEventRecord(ctx->spans.back().b, ctx->stream);
+    (void)hipEventRecord(ctx->spans.back().b, ctx->stream);
 }
 
 void put32(uint8_t *p, uint32_t v) { for (int i = 0; i < 4; i++) p[i] = (uint8_t)(v >> (8 * i)); }
@@ -152,26 +154,27 @@ int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out) {
     ctx->device = device;
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     ctx->arch = prop.gcnArchName;
+    if (const char *e = getenv("DBDE_HIP_EXPERIMENT")) ctx->exp_flags = (uint32_t)strtoul(e, nullptr, 0);
     void *p = nullptr;
     if (hipMalloc(&p, 64) != hipSuccess) { delete ctx; return DBDE_HIP_ERR_HIP; }
     ctx->sticky = reinterpret_cast<uint32_t *>(p);
     ctx->scratch64 = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(p) + 16);
-    if (hipMemsetAsync(p, 0, 64, ctx->stream) != hipSuccess) { hipFree(p); delete ctx; return DBDE_HIP_ERR_HIP; }
+    if (hipMemsetAsync(p, 0, 64, ctx->stream) != hipSuccess) { (void)hipFree(p); delete ctx; return DBDE_HIP_ERR_HIP; }
     *out = ctx;
     return DBDE_HIP_OK;
 }
 
 void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    for (auto &s : ctx->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    if (ctx->lb) hipFree(ctx->lb);
-    if (ctx->chunk_off) hipFree(ctx->chunk_off);
-    if (ctx->frame_ok) hipFree(ctx->frame_ok);
-    if (ctx->sticky) hipFree(ctx->sticky);
-    if (ctx->st_img) hipFree(ctx->st_img);
-    if (ctx->st_pack) hipFree(ctx->st_pack);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    if (ctx->lb) (void)hipFree(ctx->lb);
+    if (ctx->chunk_off) (void)hipFree(ctx->chunk_off);
+    if (ctx->frame_ok) (void)hipFree(ctx->frame_ok);
+    if (ctx->sticky) (void)hipFree(ctx->sticky);
+    if (ctx->st_img) (void)hipFree(ctx->st_img);
+    if (ctx->st_pack) (void)hipFree(ctx->st_pack);
     delete ctx;
 }
 
@@ -265,6 +268,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.T = g.T;
     p.chunks_per_frame = g.cpf;
     p.n_chunks = n_chunks;
+    p.flags = ctx->exp_flags;
     const bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);
@@ -287,7 +291,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     const uint64_t n_chunks64 = (uint64_t)n_frames * g.cpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64, sizeof(uint32_t));
+    int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64 + (size_t)n_frames, sizeof(uint32_t));
     if (rc) return rc;
     rc = grow(ctx, ctx->frame_ok, ctx->frame_ok_n, (size_t)n_frames, sizeof(uint32_t));
     if (rc) return rc;
@@ -546,8 +550,8 @@ int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[3], uint64_t launches[3], 
             ctx->acc_ms[s.kind] += t;
             ctx->acc_n[s.kind] += 1;
         }
-        hipEventDestroy(s.a);
-        hipEventDestroy(s.b);
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
     }
     ctx->spans.clear();
     for (int k = 0; k < 3; k++) {

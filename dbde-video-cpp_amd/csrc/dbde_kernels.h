@@ -35,13 +35,14 @@ struct EncParams {
     int W, H;
     uint32_t w, h, T;              // tiles across, down, total
     uint32_t chunks_per_frame, n_chunks;
+    uint32_t flags;                // bit 0: experiment, static chunk order (see dbde_capi.cpp)
 };
 
 struct DecParams {
     const uint8_t *stream;
     const uint64_t *frame_offsets;  // [n_frames] byte offset of each frame header
     uint8_t *images;
-    const uint32_t *chunk_off;      // [n_chunks] payload word offset of each chunk inside its frame
+    const uint32_t *chunk_off;      // [n_frames][chunks_per_frame + 1] payload word offset of each chunk inside its frame (+ total)
     const uint32_t *frame_ok;       // [n_frames] 1 = frame data validated
     uint64_t frame_pixels;
     int W, H;
@@ -53,7 +54,7 @@ struct IdxParams {
     const uint8_t *stream;
     const uint64_t *frame_offsets;
     uint64_t stream_bytes;
-    uint32_t *chunk_off;            // out [n_frames * chunks_per_frame]
+    uint32_t *chunk_off;            // out [n_frames][chunks_per_frame + 1]
     uint32_t *frame_ok;             // out [n_frames]
     void *results;                  // optional dbde_hip_frame_result[n_frames]
     uint32_t T, chunks_per_frame;

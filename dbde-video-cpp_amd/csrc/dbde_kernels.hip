@@ -67,6 +67,15 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *s_wave
     return base + incl;
 }
 
+// LDS staging images are XOR-swizzled at 16-byte slot granularity so that the regular lane
+// strides of uniform-depth content (lane stride = 2*depth qwords; 128 B for depth 8) do not
+// pile onto one bank.  Both are involutions that only permute slots inside an aligned group.
+__device__ __forceinline__ uint32_t swz8(uint32_t slot) { return slot ^ ((slot >> 3) & 7u); }      // 128-B groups
+__device__ __forceinline__ uint32_t swz16(uint32_t slot) { return slot ^ ((slot >> 4) & 15u); }    // 256-B groups
+// qword index -> swizzled qword index (the half inside the slot is kept)
+__device__ __forceinline__ uint32_t swzq8(uint32_t q) { return (swz8(q >> 1) << 1) | (q & 1u); }
+__device__ __forceinline__ uint32_t swzq16(uint32_t q) { return (swz16(q >> 1) << 1) | (q & 1u); }
+
 // x86-64 `(uint64_t)double` as g++ compiles it (dbde_util.cpp:334): cvttsd2si below 2^63,
 // else cvttsd2si(v - 2^63) ^ 2^63; out-of-range and NaN give the "integer indefinite".
 __device__ __forceinline__ uint64_t f64_to_u64_x86(double v) {
@@ -113,7 +122,7 @@ __device__ __forceinline__ void load_tile_generic(const uint8_t *img, int W, int
 
 // Subtract the minimum, pack each row to 8*d bits, concatenate rows into d U64 words in LDS.
 __device__ __forceinline__ void pack_tile_to_lds(const uint32_t (&v)[16], uint32_t mn, uint32_t d,
-                                                 uint64_t *dst) {
+                                                 uint64_t *s_out, uint32_t q) {
     const uint32_t m4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
     Funnel fn;
     fn.reset();
@@ -121,7 +130,7 @@ __device__ __forceinline__ void pack_tile_to_lds(const uint32_t (&v)[16], uint32
     for (int r = 0; r < 8; r++) {
         uint64_t row = pack_row(v[2 * r] - m4, v[2 * r + 1] - m4, d);
         uint64_t word;
-        if (fn.push(row, 8u * d, word)) *dst++ = word;
+        if (fn.push(row, 8u * d, word)) { s_out[swzq8(q)] = word; q++; }
     }
 }
 
@@ -184,9 +193,14 @@ __global__ __launch_bounds__(kBlockThreads) void encode_kernel(EncParams p) {
 
     // Chunks are claimed in ticket order, so every predecessor of a claimed chunk has been
     // claimed by a workgroup that is already running: look-back cannot wait on unstarted work.
-    if (tid == 0) s_bcast[0] = atomicAdd(&p.ctrl[0], 1u);
-    __syncthreads();
-    const uint32_t c = s_bcast[0];
+    uint32_t c;
+    if (p.flags & 1u) {   // EXPERIMENT ONLY: dispatch order taken as chunk order (not contract-safe)
+        c = blockIdx.x;
+    } else {
+        if (tid == 0) s_bcast[0] = atomicAdd(&p.ctrl[0], 1u);
+        __syncthreads();
+        c = s_bcast[0];
+    }
     if (c >= p.n_chunks) return;
     const uint32_t f = c / p.chunks_per_frame;
     const uint32_t cf = c - f * p.chunks_per_frame;
@@ -238,8 +252,8 @@ __global__ __launch_bounds__(kBlockThreads) void encode_kernel(EncParams p) {
     }
 
     // ---- pack into LDS (independent of the look-back) -------------------------------------
-    pack_tile_to_lds(va, mnA, dA, s_out + offA);
-    pack_tile_to_lds(vb, mnB, dB, s_out + offB);
+    pack_tile_to_lds(va, mnA, dA, s_out, offA);
+    pack_tile_to_lds(vb, mnB, dB, s_out, offB);
 
     // ---- chunk offset inside the frame and the launch -------------------------------------
     if (wave == 0) {
@@ -290,22 +304,22 @@ __global__ __launch_bounds__(kBlockThreads) void encode_kernel(EncParams p) {
     if (ALIGNED_OUT) {
         const uint32_t q0 = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);   // 1: dst is 8 mod 16
         const uint32_t lead = q0 < chunk_total ? q0 : chunk_total;
-        if (lead && tid == 0) *reinterpret_cast<uint64_t *>(dst) = s_out[0];
+        if (lead && tid == 0) *reinterpret_cast<uint64_t *>(dst) = s_out[swzq8(0)];
         const uint32_t rest = chunk_total - lead;
         const uint32_t npairs = rest >> 1;
         for (uint32_t i = tid; i < npairs; i += kBlockThreads) {
             const uint32_t k = lead + 2u * i;
             ulonglong2 v2;
-            v2.x = s_out[k];
-            v2.y = s_out[k + 1];
+            v2.x = s_out[swzq8(k)];
+            v2.y = s_out[swzq8(k + 1u)];
             *reinterpret_cast<ulonglong2 *>(dst + 8ull * k) = v2;
         }
         if ((rest & 1u) && tid == kBlockThreads - 1) {
             const uint32_t k = chunk_total - 1u;
-            *reinterpret_cast<uint64_t *>(dst + 8ull * k) = s_out[k];
+            *reinterpret_cast<uint64_t *>(dst + 8ull * k) = s_out[swzq8(k)];
         }
     } else {
-        for (uint32_t k = tid; k < chunk_total; k += kBlockThreads) store_u64_any(dst + 8ull * k, s_out[k]);
+        for (uint32_t k = tid; k < chunk_total; k += kBlockThreads) store_u64_any(dst + 8ull * k, s_out[swzq8(k)]);
     }
 
     // ---- frame header and the I32 fields (dbde_util.cpp:140-146, 182-196) -------------------
@@ -441,10 +455,12 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
         total += v;
     }
     uint32_t run = base + incl - local;
+    uint32_t *co = p.chunk_off + (size_t)f * (cpf + 1u);
     for (uint32_t k = k0; k < k0 + seg && k < cpf; k++) {
-        p.chunk_off[(size_t)f * cpf + k] = run;
+        co[k] = run;
         run += s_sum[k];
     }
+    if (tid == 0) co[cpf] = total;
 
     if (tid == 0) {
         bool ok = in_range;
@@ -487,21 +503,19 @@ hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s) 
     return hipGetLastError();
 }
 
-// Row r of a tile is the 8*d-bit integer at byte (r*d) of the tile payload: fetch it from the
-// LDS image with three aligned dword reads and a funnel shift, expand, add the minimum.
-__device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_in, uint32_t byte_base, uint32_t d,
+// Row r of a tile is the 8*d-bit integer at byte (r*d) of the tile payload: fetch the two
+// qwords that hold it from the swizzled LDS image, funnel-shift, expand, add the minimum.
+__device__ __forceinline__ void unpack_tile_from_lds(const uint64_t *s_in, uint32_t byte_base, uint32_t d,
                                                      uint32_t mn, uint32_t (&v)[16]) {
     const uint32_t m4 = mn * 0x01010101u;
     const uint64_t keep = d >= 8u ? ~0ull : ((1ull << (8u * d)) - 1ull);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t a = byte_base + d * (uint32_t)r;
-        const uint32_t *wp = reinterpret_cast<const uint32_t *>(s_in + (a & ~3u));
-        const uint32_t sh = (a & 3u) * 8u;
-        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-        const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        const uint64_t row = (((uint64_t)hi << 32) | lo) & keep;
+        const uint32_t q = a >> 3;
+        const uint32_t sh = (a & 7u) * 8u;
+        const uint64_t lo = s_in[swzq16(q)], hi = s_in[swzq16(q + 1u)];
+        const uint64_t row = (sh ? ((lo >> sh) | (hi << (64u - sh))) : lo) & keep;
         uint32_t x, y;
         expand_row(row, d, x, y);
         v[2 * r] = add_bytes(x, m4);
@@ -532,40 +546,62 @@ __device__ __forceinline__ void store_tile_generic(uint8_t *img, int W, int H, u
     }
 }
 
-constexpr uint32_t kDecLdsBytes = kMaxChunkWords * 8 + 64;   // payload + alignment shift + over-read slack
+// LDS image of a chunk's payload: up to 15 bytes of alignment shift + 32 KiB + one qword of
+// over-read, rounded up to whole 256-byte swizzle groups.
+constexpr uint32_t kDecLdsSlots = ((15u + kMaxChunkWords * 8u + 8u + 15u) / 16u + 15u) / 16u * 16u;
+constexpr int kDecMaxPieces = (kDecLdsSlots + kBlockThreads - 1) / kBlockThreads;   // 16-B pieces per thread
 
 template <bool FAST_IMG>
 __global__ __launch_bounds__(kBlockThreads) void decode_kernel(DecParams p) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kDecLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint64_t s_in[kDecLdsSlots * 2];
     __shared__ uint32_t s_wave_tot[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c = blockIdx.x;
     const uint32_t f = c / p.chunks_per_frame;
     const uint32_t cf = c - f * p.chunks_per_frame;
-    if (!p.frame_ok[f]) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
+    // everything the address arithmetic needs, requested together
+    const uint32_t ok = p.frame_ok[f];
+    const uint64_t foff = p.frame_offsets[f];
+    const uint32_t *co = p.chunk_off + (size_t)f * (p.chunks_per_frame + 1u) + cf;
+    const uint32_t w_begin = co[0], w_end = co[1];
+    if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
 
-    const uint8_t *fb = p.stream + p.frame_offsets[f];
+    const uint8_t *fb = p.stream + foff;
     const uint32_t t0 = cf * kChunkTiles + 2u * (uint32_t)tid;
     const bool hasA = t0 < p.T, hasB = t0 + 1u < p.T;
     const uint8_t *depth_arr = fb + 24;
     const uint8_t *min_arr = fb + 28 + p.T;
+
+    // ---- issue the payload loads (16 B per lane, source aligned down) BEFORE the depth bytes
+    //      are needed: the chunk's extent comes from the index, not from a scan of the depths ----
+    const uint32_t chunk_words = w_end - w_begin;
+    const uint8_t *src = fb + 32ull + 2ull * p.T + 8ull * w_begin;
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+    const uint8_t *asrc = src - shift;
+    const uint32_t n16 = (shift + 8u * chunk_words + 15u) >> 4;
+    // LDS-DMA (global_load_lds_dwordx4): physical slot i of the image <- logical slot swz16(i)
+    // of the stream; the destination is wave-uniform base + lane*16, the permutation stays
+    // inside one 256-byte group so the source side remains coalesced.  No staging registers.
+    const uint32_t n16r = (n16 + 15u) & ~15u;
+#pragma unroll
+    for (int j = 0; j < kDecMaxPieces; j++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)j * kBlockThreads;
+        const uint32_t src_slot = swz16(i);
+        if (i < n16r && src_slot < n16) {
+            const uint32_t wave_slot0 = (uint32_t)j * kBlockThreads + (uint32_t)wave * 64u;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(asrc + 16ull * src_slot),
+                (__attribute__((address_space(3))) void *)(&s_in[2u * wave_slot0]), 16, 0, 0);
+        }
+    }
     uint32_t dA = 0, dB = 0, mA = 0, mB = 0;
     if (hasA) { dA = depth_arr[t0]; mA = min_arr[t0]; }
     if (hasB) { dB = depth_arr[t0 + 1]; mB = min_arr[t0 + 1]; }
 
-    uint32_t chunk_total;
-    const uint32_t incl = block_scan_incl(dA + dB, s_wave_tot, lane, wave, chunk_total);
+    uint32_t chunk_total;   // equals chunk_words for a validated frame
+    const uint32_t incl = block_scan_incl(dA + dB, s_wave_tot, lane, wave, chunk_total);   // barrier inside
     const uint32_t offA = incl - (dA + dB), offB = offA + dA;
-
-    // ---- stage the chunk's payload: global -> LDS, 16 B per lane, source aligned down ---------
-    const uint8_t *src = fb + 32ull + 2ull * p.T + 8ull * p.chunk_off[c];
-    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
-    const uint8_t *asrc = src - shift;
-    const uint32_t n16 = (shift + 8u * chunk_total + 15u) >> 4;
-    for (uint32_t i = tid; i < n16; i += kBlockThreads)
-        *reinterpret_cast<uint4 *>(s_in + 16u * i) = *reinterpret_cast<const uint4 *>(asrc + 16ull * i);
-    __syncthreads();
 
     uint32_t va[16], vb[16];
     unpack_tile_from_lds(s_in, shift + 8u * offA, dA, mA, va);

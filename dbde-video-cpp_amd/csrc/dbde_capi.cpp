@@ -56,6 +56,8 @@ struct dbde_hip_ctx {
     size_t st_pack_bytes = 0;
     // timing
     uint32_t exp_flags = 0;          // $DBDE_HIP_EXPERIMENT (tuning experiments only)
+    uint32_t enc_grid = 0;           // resident workgroups for the persistent encoder
+    uint64_t *diag = nullptr;        // [16] phase cycle sums of diagnostic launches
     bool timing = false;
     std::vector<TimedSpan> spans;
     double acc_ms[3] = {0, 0, 0};
@@ -154,12 +156,18 @@ int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out) {
     ctx->device = device;
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     ctx->arch = prop.gcnArchName;
+    {
+        int per_cu = encode_blocks_per_cu();
+        if (const char *g = getenv("DBDE_HIP_ENC_BLOCKS_PER_CU")) per_cu = atoi(g) > 0 ? atoi(g) : per_cu;
+        ctx->enc_grid = (uint32_t)(per_cu * prop.multiProcessorCount);
+    }
     if (const char *e = getenv("DBDE_HIP_EXPERIMENT")) ctx->exp_flags = (uint32_t)strtoul(e, nullptr, 0);
     void *p = nullptr;
-    if (hipMalloc(&p, 64) != hipSuccess) { delete ctx; return DBDE_HIP_ERR_HIP; }
+    if (hipMalloc(&p, 64 + 128) != hipSuccess) { delete ctx; return DBDE_HIP_ERR_HIP; }
     ctx->sticky = reinterpret_cast<uint32_t *>(p);
     ctx->scratch64 = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(p) + 16);
-    if (hipMemsetAsync(p, 0, 64, ctx->stream) != hipSuccess) { (void)hipFree(p); delete ctx; return DBDE_HIP_ERR_HIP; }
+    ctx->diag = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(p) + 64);
+    if (hipMemsetAsync(p, 0, 64 + 128, ctx->stream) != hipSuccess) { (void)hipFree(p); delete ctx; return DBDE_HIP_ERR_HIP; }
     *out = ctx;
     return DBDE_HIP_OK;
 }
@@ -219,7 +227,8 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
     const uint64_t maxf = 32ull + 66ull * g.T;
-    const uint64_t n_chunks64 = (uint64_t)n_frames * g.cpf;
+    const uint32_t enc_cpf = (g.T + kEncChunkTiles - 1) / kEncChunkTiles;
+    const uint64_t n_chunks64 = (uint64_t)n_frames * enc_cpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: too many chunks in one call");
     if (slot_stride) {
         if (slot_stride < maxf) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: slot_stride below the worst case");
@@ -235,7 +244,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     const uint32_t n_chunks = (uint32_t)n_chunks64;
-    const size_t lb_need = 16 + 8 * (size_t)n_chunks;
+    const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
     {
         size_t have = ctx->lb_bytes;
         uint8_t *p = reinterpret_cast<uint8_t *>(ctx->lb);
@@ -244,7 +253,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         ctx->lb = p;
         ctx->lb_bytes = have;
     }
-    const size_t zero_bytes = (lb_need + 15) & ~(size_t)15;
+    const size_t zero_bytes = lb_need;
     span_begin(ctx, 0);
     HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, zero_bytes, ctx->stream));
 
@@ -266,9 +275,10 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.w = g.w;
     p.h = g.h;
     p.T = g.T;
-    p.chunks_per_frame = g.cpf;
+    p.chunks_per_frame = enc_cpf;
     p.n_chunks = n_chunks;
     p.flags = ctx->exp_flags;
+    p.grid_blocks = ctx->enc_grid;
     const bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);

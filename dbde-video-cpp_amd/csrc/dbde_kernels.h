@@ -10,6 +10,8 @@ namespace dbde {
 constexpr int kBlockThreads = 256;
 constexpr uint32_t kChunkTiles = 512;
 constexpr uint32_t kMaxChunkWords = kChunkTiles * 8;   // U64 words of payload per chunk, worst case
+// The encoder walks larger chunks (fewer ticket draws): one 512-thread workgroup per 1024 tiles.
+constexpr uint32_t kEncChunkTiles = 1024;
 
 // Decoupled look-back record, one per chunk, 64 bits, written and read with relaxed
 // agent-scope atomics (the record IS the flag, so no fence is needed):
@@ -35,7 +37,8 @@ struct EncParams {
     int W, H;
     uint32_t w, h, T;              // tiles across, down, total
     uint32_t chunks_per_frame, n_chunks;
-    uint32_t flags;                // bit 0: experiment, static chunk order (see dbde_capi.cpp)
+    uint32_t flags;                // reserved for tuning experiments
+    uint32_t grid_blocks;          // resident workgroups of the persistent encoder
 };
 
 struct DecParams {
@@ -69,6 +72,7 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 };
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
+int encode_blocks_per_cu();
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s);
 hipError_t launch_synth(int mode, uint64_t seed, uint64_t first_frame, int n_frames, int W, int H,

@@ -49,6 +49,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// Wave-wide inclusive scan with DPP row shifts / row broadcasts (gfx9 wave64 idiom): no LDS.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    uint32_t t = x;
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xF, 0xF, false);   // row_shr:1
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xF, 0xF, false);   // row_shr:2
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, false);   // row_shr:4
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xF, false);   // row_shr:8
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return t;
+}
+
 // Inclusive scan of one value per lane across the 256-thread block.
 // Returns this lane's inclusive prefix; block_total = sum over the block.
 __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *s_wave_tot, int lane, int wave,
@@ -120,101 +132,205 @@ __device__ __forceinline__ void load_tile_generic(const uint8_t *img, int W, int
     }
 }
 
-// Subtract the minimum, pack each row to 8*d bits, concatenate rows into d U64 words in LDS.
-__device__ __forceinline__ void pack_tile_to_lds(const uint32_t (&v)[16], uint32_t mn, uint32_t d,
-                                                 uint64_t *s_out, uint32_t q) {
-    const uint32_t m4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
-    Funnel fn;
-    fn.reset();
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint64_t row = pack_row(v[2 * r] - m4, v[2 * r + 1] - m4, d);
-        uint64_t word;
-        if (fn.push(row, 8u * d, word)) { s_out[swzq8(q)] = word; q++; }
+// Chunk offsets: a central in-order scan instead of a distributed look-back.
+//
+// Every chunk's payload-word count is published by its workers as an AGG record, in parallel
+// and without waiting on anything.  ONE wave in the whole launch (the scanner: the scout wave of
+// whichever workgroup started first) walks the records in chunk order, 512 per round with all
+// loads in flight at once, turns them into inclusive prefixes with a wave scan, and overwrites
+// each record with its INC form.  A chunk's scout only polls its own 8-byte record.  This
+// moves >100 chunks/us with a few KB of polling per round, where a decoupled look-back (every
+// chunk re-reading a window of predecessors until it meets an INC) advanced only one window
+// per hop latency and flooded the fabric with polls.  While passing, the scanner also writes
+// what depends only on prefixes: frame header, the I32 fields, per-frame offsets and sizes.
+//
+// Records (8 B, relaxed agent-scope atomics, the record is its own flag):
+//   AGG : [63:62] = 1, [31:0] payload words of the chunk
+//   INC : [63:62] = 2, [61:32] payload words of the frame up to and including the chunk,
+//                      [31:0]  payload words of the launch up to and including it (mod 2^32)
+template <bool ALIGNED_OUT>
+__device__ __forceinline__ void scanner_frame_fields(const EncParams &p, uint32_t f, uint32_t cf, uint32_t inf_incl,
+                                                     uint32_t frame_start_glob) {
+    const uint64_t meta = 32ull + 2ull * p.T;
+    const uint64_t frame_base = p.slot_stride ? (uint64_t)f * p.slot_stride
+                                              : (uint64_t)f * meta + 8ull * (uint64_t)frame_start_glob;
+    uint8_t *fb = p.out + frame_base;
+    if (cf == 0u) {   // frame header + the two I32 T fields (dbde_util.cpp:140-143, 182-196)
+        const uint64_t index = p.indices ? p.indices[f] : p.first_index + f;
+        const uint64_t el = p.elapsed_ns ? p.elapsed_ns[f] : 0ull;
+        const uint64_t elbits = (uint64_t)__double_as_longlong(__ull2double_rn(el));   // trap T1: F64 on the wire
+        if (ALIGNED_OUT) {
+            uint32_t *h = reinterpret_cast<uint32_t *>(fb);
+            h[0] = 2u;
+            h[1] = (uint32_t)index; h[2] = (uint32_t)(index >> 32);
+            h[3] = (uint32_t)elbits; h[4] = (uint32_t)(elbits >> 32);
+            h[5] = p.T;
+            *reinterpret_cast<uint32_t *>(fb + 24 + p.T) = p.T;
+        } else {
+            store_u32_bytes(fb, 2u);
+            store_u32_bytes(fb + 4, (uint32_t)index); store_u32_bytes(fb + 8, (uint32_t)(index >> 32));
+            store_u32_bytes(fb + 12, (uint32_t)elbits); store_u32_bytes(fb + 16, (uint32_t)(elbits >> 32));
+            store_u32_bytes(fb + 20, p.T);
+            store_u32_bytes(fb + 24 + p.T, p.T);
+        }
+        if (p.frame_offsets) p.frame_offsets[f] = frame_base;
+    }
+    if (cf == p.chunks_per_frame - 1u) {   // I32 n64 (dbde_util.cpp:144-146,179)
+        if (ALIGNED_OUT) *reinterpret_cast<uint32_t *>(fb + 28 + 2ull * p.T) = inf_incl;
+        else store_u32_bytes(fb + 28 + 2ull * p.T, inf_incl);
+        if (p.frame_bytes) p.frame_bytes[f] = meta + 8ull * inf_incl;
     }
 }
 
-// Decoupled look-back executed by one full wave.  Walks 64 predecessors at a time, nearest
-// first.  Chunks below lo_bound do not exist (prefix 0).  Returns false on POISON / time-out.
-__device__ __forceinline__ bool lookback(const u64a *state, uint32_t c, uint32_t frame_first,
-                                         uint32_t lo_bound, int lane, uint32_t &inframe_excl,
-                                         uint32_t &global_excl) {
-    uint32_t inf = 0, glob = 0;
-    long long top = (long long)c - 1;
-    const uint64_t t_start = wall_clock64();
-    for (;;) {
-        const long long idx = top - lane;
-        const bool real = idx >= (long long)lo_bound;
-        uint32_t spins = 0;
-        for (;;) {
-            u64a word = kStInc;   // virtual predecessor: inclusive prefix 0
-            if (real) word = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t st = (uint32_t)(word >> 62);
-            const uint64_t incm = __ballot(st == 2u);
-            const uint64_t rdy = __ballot(st != 0u);
-            const uint64_t bad = __ballot(st == 3u);
-            const uint64_t low = incm & (0ull - incm);               // nearest INC lane, as a bit
-            const uint64_t need = incm ? ((low << 1) - 1ull) : ~0ull;  // lanes 0..first INC
-            if (bad & need) return false;
-            if ((rdy & need) == need) {
-                const int first = incm ? (__ffsll((long long)incm) - 1) : 64;
-                uint32_t g = 0, i = 0;
-                const bool same_frame = real && idx >= (long long)frame_first;
-                if (lane < first) {          // AGG records
-                    g = (uint32_t)word;
-                    i = same_frame ? g : 0u;
-                } else if (lane == first) {  // the INC record that ends the walk
-                    g = (uint32_t)word;
-                    i = same_frame ? (uint32_t)((word >> 32) & 0x3FFFFFFFull) : 0u;
+constexpr int kScanLoads = 8;   // records per lane per round (512 per round)
+
+template <bool ALIGNED_OUT>
+__device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t F = 0;                    // first record not yet converted
+    uint32_t carry_glob = 0;           // launch-wide payload words before record F
+    uint32_t frame_start_glob = 0;     // launch-wide payload words before the frame that contains record F
+    uint64_t t_progress = wall_clock64();
+    while (F < p.n_chunks) {
+        u64a w[kScanLoads];
+#pragma unroll
+        for (int j = 0; j < kScanLoads; j++) {
+            const uint32_t idx = F + 64u * (uint32_t)j + (uint32_t)lane;
+            w[j] = idx < p.n_chunks ? __hip_atomic_load(&p.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        uint32_t done = 0;
+        bool stop = false;
+#pragma unroll
+        for (int j = 0; j < kScanLoads; j++) {
+            if (!stop) {
+                const uint32_t base = F + 64u * (uint32_t)j;
+                const uint32_t idx = base + (uint32_t)lane;
+                const bool ready = (uint32_t)(w[j] >> 62) == 1u;
+                const uint64_t rdy = __ballot(ready);
+                const uint32_t cnt = rdy == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~rdy);   // leading ready lanes
+                if (cnt != 0u) {
+                    const bool act = (uint32_t)lane < cnt;
+                    const uint32_t t = act ? (uint32_t)w[j] : 0u;
+                    const uint32_t incl = wave_scan_incl(t);
+                    const uint32_t g_incl = carry_glob + incl, g_excl = g_incl - t;
+                    // launch-wide prefix at the start of this lane's frame: inside the window it is
+                    // the exclusive prefix of the lane holding the frame's first chunk
+                    const uint32_t f = idx / p.chunks_per_frame;
+                    const uint32_t fstart = f * p.chunks_per_frame;
+                    const uint32_t from_lane = __shfl(g_excl, fstart >= base ? (int)(fstart - base) : 0, 64);
+                    const uint32_t gs = fstart >= base ? from_lane : frame_start_glob;
+                    const uint32_t inf_incl = g_incl - gs;
+                    if (act) {
+                        const u64a rec = kStInc | ((u64a)(inf_incl & 0x3FFFFFFFu) << 32) | (u64a)g_incl;
+                        __hip_atomic_store(&p.state[idx], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t cf = idx - fstart;
+                        if (cf == 0u || cf == p.chunks_per_frame - 1u)
+                            scanner_frame_fields<ALIGNED_OUT>(p, f, cf, inf_incl, gs);
+                    }
+                    // carries for the record after the last converted one
+                    const uint32_t last = cnt - 1u;
+                    carry_glob = __builtin_amdgcn_readlane(g_incl, last);
+                    const uint32_t nidx = base + cnt;
+                    const uint32_t nf_start = (nidx / p.chunks_per_frame) * p.chunks_per_frame;
+                    // frame of the next record starts at nf_start: its prefix is known if nf_start <= nidx
+                    if (nf_start == nidx) frame_start_glob = carry_glob;
+                    else if (nf_start >= base) frame_start_glob = __builtin_amdgcn_readlane(g_excl, nf_start - base);
+                    done += cnt;
                 }
-                glob += wave_sum(g);
-                inf += wave_sum(i);
-                if (incm) {
-                    inframe_excl = inf;
-                    global_excl = glob;
-                    return true;
-                }
-                top -= 64;
-                break;
+                if (cnt < 64u) stop = true;
             }
-            if (++spins > 64u && (wall_clock64() - t_start) > 200000000ull) return false;   // 2 s at 100 MHz
-            __builtin_amdgcn_s_sleep(2);
+        }
+        if (done) {
+            F += done;
+            t_progress = wall_clock64();
+        } else {
+            if (wall_clock64() - t_progress > 200000000ull) {   // 2 s without progress: give up
+                if (lane == 0) atomicOr(p.sticky, 1u);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(4);
         }
     }
 }
 
-template <bool FAST_IN, bool ALIGNED_OUT>
-__global__ __launch_bounds__(kBlockThreads) void encode_kernel(EncParams p) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_out[kMaxChunkWords];   // 32 KiB payload staging
-    __shared__ uint32_t s_wave_tot[4];
-    __shared__ uint32_t s_bcast[4];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // Chunks are claimed in ticket order, so every predecessor of a claimed chunk has been
-    // claimed by a workgroup that is already running: look-back cannot wait on unstarted work.
-    uint32_t c;
-    if (p.flags & 1u) {   // EXPERIMENT ONLY: dispatch order taken as chunk order (not contract-safe)
-        c = blockIdx.x;
-    } else {
-        if (tid == 0) s_bcast[0] = atomicAdd(&p.ctrl[0], 1u);
-        __syncthreads();
-        c = s_bcast[0];
+// Scout side: wait until the scanner has converted this chunk's own record.
+__device__ __forceinline__ bool wait_inc(const u64a *state, uint32_t c, uint32_t &inf_incl, uint32_t &glob_incl) {
+    const uint64_t t_start = wall_clock64();
+    for (uint32_t spins = 0;; spins++) {
+        const u64a w = __hip_atomic_load(&state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st = (uint32_t)(w >> 62);
+        if (st == 2u) {
+            inf_incl = (uint32_t)((w >> 32) & 0x3FFFFFFFull);
+            glob_incl = (uint32_t)w;
+            return true;
+        }
+        if (st == 3u) return false;
+        if (spins > 64u && (wall_clock64() - t_start) > 300000000ull) return false;   // 3 s at 100 MHz
+        __builtin_amdgcn_s_sleep(8);
     }
-    if (c >= p.n_chunks) return;
-    const uint32_t f = c / p.chunks_per_frame;
-    const uint32_t cf = c - f * p.chunks_per_frame;
-    const uint32_t t0 = cf * kChunkTiles + 2u * (uint32_t)tid;
-    const bool hasA = t0 < p.T, hasB = t0 + 1u < p.T;
-    const uint8_t *img = p.images + (size_t)f * p.frame_pixels;
+}
 
-    // ---- load two tiles -----------------------------------------------------------------
-    uint32_t va[16], vb[16];
+// ---------------------------------------------------------------------------------------
+// ENCODE kernel: persistent, software-pipelined
+// ---------------------------------------------------------------------------------------
+// A workgroup = 8 waves (two per SIMD, so 2 workgroups per CU are resident), alive for the
+// whole launch, walking chunks (1024 consecutive tiles) in ticket order.  (Chunks twice the
+// decoder's size halve the rate of ticket draws, which all hit one address.)  Three chunks are in
+// flight per workgroup:
+//     nxt : image loads in flight (16 B per lane per row, registers R1), issued at the top
+//     cur : pixels in R0 -> min/max, depth, wave scan, AGG record, pack into the wave's LDS region
+//     prev: packed payload in LDS -> stored once its mailbox (INC record) has been read
+// Order inside an iteration (what makes it fast):
+//   1. lane 0 polls prev's mailbox and draws the next ticket BEFORE any load of this iteration
+//      is issued: a wave's vector-memory results return in issue order, so a poll issued behind
+//      the prefetch loads would wait for them.  prev's AGG was published a whole iteration ago,
+//      so the scanner has normally answered already.
+//   2. all waves issue nxt's image loads (consumed at the end of the iteration).
+//   3. statistics of cur; the last wave to finish publishes cur's AGG record immediately.
+//   4. ONE workgroup barrier: wave totals, prev's offsets and the next chunk id become visible.
+//   5. each wave stores its own contiguous part of prev (LDS -> global, 16 B per lane) and packs
+//      cur over it.  The LDS image is private to the wave, so this needs no workgroup barrier.
+// Forward progress: chunks are claimed in ticket order by running workgroups, AGG records are
+// published without waiting on anything, the scanner is a running workgroup by construction:
+// the smallest unfinished chunk can always finish.
+constexpr int kEncWaves = kEncChunkTiles / 128;                  // two tiles per lane
+constexpr int kEncThreads = 64 * kEncWaves;
+constexpr uint32_t kWaveWords = 128 * 8;                         // 1024 U64 = 8 KiB per wave
+
+struct EncShared {
+    uint64_t pay[kEncWaves][kWaveWords];     // swizzled (swzq8) payload image of each wave
+    uint32_t tot[2][kEncWaves];              // [parity][wave] payload words of cur per wave
+    uint32_t lb[2][4];                       // [parity] {in-frame prefix, launch prefix, ok, next chunk id}
+    uint32_t acc[2];                         // [parity] arrivals << 24 | sum of the waves' totals
+    uint32_t boot[2];                        // role / first two chunk ids
+};
+
+struct ChunkRef {
+    uint32_t c, f, cf, t0;
+    bool valid, hasA, hasB;
+};
+
+__device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, int tidw) {
+    ChunkRef k;
+    k.c = c;
+    k.valid = c < p.n_chunks;
+    k.f = k.valid ? c / p.chunks_per_frame : 0u;
+    k.cf = k.valid ? c - k.f * p.chunks_per_frame : 0u;
+    k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
+    k.hasA = k.valid && k.t0 < p.T;
+    k.hasB = k.valid && k.t0 + 1u < p.T;
+    return k;
+}
+
+template <bool FAST_IN>
+__device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
+                                           uint32_t (&vb)[16]) {
 #pragma unroll
     for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
+    const uint8_t *img = p.images + (size_t)k.f * p.frame_pixels;
     if (FAST_IN) {   // W % 16 == 0, base 16-aligned: both tiles in one strip, one 16-B load per row
-        if (hasA) {
-            const uint32_t ty = t0 / p.w, tx = t0 - ty * p.w;
+        if (k.hasA) {
+            const uint32_t ty = k.t0 / p.w, tx = k.t0 - ty * p.w;
             const uint8_t *base = img + (size_t)(8u * tx);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -226,140 +342,244 @@ __global__ __launch_bounds__(kBlockThreads) void encode_kernel(EncParams p) {
             }
         }
     } else {
-        if (hasA) load_tile_generic(img, p.W, p.H, p.w, t0, va);
-        if (hasB) load_tile_generic(img, p.W, p.H, p.w, t0 + 1u, vb);
+        if (k.hasA) load_tile_generic(img, p.W, p.H, p.w, k.t0, va);
+        if (k.hasB) load_tile_generic(img, p.W, p.H, p.w, k.t0 + 1u, vb);
     }
+}
 
-    // ---- per-tile statistics (dbde_util.cpp:30-68) ---------------------------------------
-    uint32_t mnA, mxA, mnB, mxB;
-    tile_minmax(va, mnA, mxA);
-    tile_minmax(vb, mnB, mxB);
-    const uint32_t dA = hasA ? depth_of_range(mxA - mnA) : 0u;
-    const uint32_t dB = hasB ? depth_of_range(mxB - mnB) : 0u;
+// One tile row -> 8*d-bit integer with two v_dot4_u32_u8 per 4 pixels (weights 1, 2^d);
+// d == 8 (weights do not fit a byte) keeps the bytes as they are.
+__device__ __forceinline__ uint64_t pack_row_dot(uint32_t lo, uint32_t hi, uint32_t d, uint32_t w_lo, uint32_t w_hi,
+                                                 bool is8) {
+    uint32_t g0 = __builtin_amdgcn_udot4(lo, w_lo, 0u, false) | (__builtin_amdgcn_udot4(lo, w_hi, 0u, false) << (2u * d));
+    uint32_t g1 = __builtin_amdgcn_udot4(hi, w_lo, 0u, false) | (__builtin_amdgcn_udot4(hi, w_hi, 0u, false) << (2u * d));
+    g0 = is8 ? lo : g0;
+    g1 = is8 ? hi : g1;
+    return (uint64_t)g0 | ((uint64_t)g1 << (4u * d));
+}
 
-    // ---- offsets inside the chunk ---------------------------------------------------------
-    uint32_t chunk_total;
-    const uint32_t incl = block_scan_incl(dA + dB, s_wave_tot, lane, wave, chunk_total);
-    const uint32_t offA = incl - (dA + dB), offB = offA + dA;
-
-    const bool slot_mode = p.slot_stride != 0;
-    const uint32_t frame_first = f * p.chunks_per_frame;
-    const bool is_head = slot_mode ? (cf == 0u) : (c == 0u);
-    if (tid == 0) {
-        const u64a rec = is_head ? (kStInc | ((u64a)chunk_total << 32) | (u64a)chunk_total)
-                                 : (kStAgg | (u64a)chunk_total);
-        __hip_atomic_store(&p.state[c], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Subtract the minimum, pack each row to 8*d bits, concatenate rows into d U64 words of the
+// wave's LDS region starting at word q.
+__device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, uint32_t d, uint64_t *pay, uint32_t q) {
+    const uint32_t m4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
+    const uint32_t w_lo = 1u | ((1u << d) << 8), w_hi = w_lo << 16;
+    const bool is8 = d >= 8u;
+    Funnel fn;
+    fn.reset();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint64_t row = pack_row_dot(v[2 * r] - m4, v[2 * r + 1] - m4, d, w_lo, w_hi, is8);
+        uint64_t word;
+        if (fn.push(row, 8u * d, word)) { pay[swzq8(q)] = word; q++; }
     }
+}
 
-    // ---- pack into LDS (independent of the look-back) -------------------------------------
-    pack_tile_to_lds(va, mnA, dA, s_out, offA);
-    pack_tile_to_lds(vb, mnB, dB, s_out, offB);
+// Depth 8 everywhere in the wave: the payload is the min-subtracted bytes, row by row.
+__device__ __forceinline__ void pack_tile_d8(const uint32_t (&v)[16], uint32_t mn, uint64_t *pay, uint32_t q) {
+    const uint32_t m4 = mn * 0x01010101u;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        pay[swzq8(q + (uint32_t)r)] = (uint64_t)(v[2 * r] - m4) | ((uint64_t)(v[2 * r + 1] - m4) << 32);
+}
 
-    // ---- chunk offset inside the frame and the launch -------------------------------------
-    if (wave == 0) {
-        uint32_t inf = 0, glob = 0;
-        bool ok = true;
-        if (!is_head) ok = lookback(p.state, c, frame_first, slot_mode ? frame_first : 0u, lane, inf, glob);
-        if (lane == 0) {
-            if (!ok) {
-                __hip_atomic_store(&p.state[c], kStPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicOr(p.sticky, 1u);
-            } else if (!is_head) {
-                const u64a rec = kStInc | ((u64a)((inf + chunk_total) & 0x3FFFFFFFu) << 32) |
-                                 (u64a)(uint32_t)(glob + chunk_total);
-                __hip_atomic_store(&p.state[c], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_bcast[1] = inf;
-            s_bcast[2] = glob;
-            s_bcast[3] = ok ? 1u : 0u;
-        }
-    }
-    __syncthreads();
-    if (!s_bcast[3]) return;
-    const uint32_t inf = s_bcast[1], glob = s_bcast[2];
+__device__ __forceinline__ uint64_t frame_base_of(const EncParams &p, uint32_t f, uint32_t inf, uint32_t glob) {
+    const uint64_t meta = 32ull + 2ull * p.T;
+    return p.slot_stride ? (uint64_t)f * p.slot_stride : (uint64_t)f * meta + 8ull * (uint64_t)(uint32_t)(glob - inf);
+}
 
-    // ---- addresses (dbde_util.cpp:137-146 layout) ------------------------------------------
-    const uint64_t meta = 32ull + 2ull * p.T;   // frame header + three I32 + two byte arrays
-    const uint64_t frame_base = slot_mode ? (uint64_t)f * p.slot_stride
-                                          : (uint64_t)f * meta + 8ull * (uint64_t)(uint32_t)(glob - inf);
-    uint8_t *fb = p.out + frame_base;
+// Worker-side stores of one finished chunk: the per-tile depth/min bytes of this lane and the
+// wave's contiguous payload range (LDS -> global, 16 B per lane).
+template <bool ALIGNED_OUT>
+__device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkRef &k, uint32_t meta4, uint32_t wbase,
+                                                uint32_t wtot, uint32_t inf, uint32_t glob, const uint64_t *pay,
+                                                int lane) {
+    const uint64_t meta = 32ull + 2ull * p.T;
+    uint8_t *fb = p.out + frame_base_of(p, k.f, inf, glob);
     uint8_t *depth_arr = fb + 24;
     uint8_t *min_arr = fb + 28 + p.T;
-
+    const uint32_t dA = meta4 & 0xFFu, dB = (meta4 >> 8) & 0xFFu, mnA = (meta4 >> 16) & 0xFFu, mnB = meta4 >> 24;
     if (ALIGNED_OUT) {   // fb % 8 == 0 and T % 4 == 0: t0 is even, so both arrays are 2-aligned here
-        if (hasB) {
-            *reinterpret_cast<uint16_t *>(depth_arr + t0) = (uint16_t)(dA | (dB << 8));
-            *reinterpret_cast<uint16_t *>(min_arr + t0) = (uint16_t)(mnA | (mnB << 8));
-        } else if (hasA) {
-            depth_arr[t0] = (uint8_t)dA;
-            min_arr[t0] = (uint8_t)mnA;
+        if (k.hasB) {
+            *reinterpret_cast<uint16_t *>(depth_arr + k.t0) = (uint16_t)(dA | (dB << 8));
+            *reinterpret_cast<uint16_t *>(min_arr + k.t0) = (uint16_t)(mnA | (mnB << 8));
+        } else if (k.hasA) {
+            depth_arr[k.t0] = (uint8_t)dA;
+            min_arr[k.t0] = (uint8_t)mnA;
         }
     } else {
-        if (hasA) { depth_arr[t0] = (uint8_t)dA; min_arr[t0] = (uint8_t)mnA; }
-        if (hasB) { depth_arr[t0 + 1] = (uint8_t)dB; min_arr[t0 + 1] = (uint8_t)mnB; }
+        if (k.hasA) { depth_arr[k.t0] = (uint8_t)dA; min_arr[k.t0] = (uint8_t)mnA; }
+        if (k.hasB) { depth_arr[k.t0 + 1] = (uint8_t)dB; min_arr[k.t0 + 1] = (uint8_t)mnB; }
     }
-
-    // ---- payload: LDS -> global, 16 B per lane ---------------------------------------------
-    uint8_t *dst = fb + meta + 8ull * inf;
+    uint8_t *dst = fb + meta + 8ull * ((uint64_t)inf + wbase);
     if (ALIGNED_OUT) {
         const uint32_t q0 = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);   // 1: dst is 8 mod 16
-        const uint32_t lead = q0 < chunk_total ? q0 : chunk_total;
-        if (lead && tid == 0) *reinterpret_cast<uint64_t *>(dst) = s_out[swzq8(0)];
-        const uint32_t rest = chunk_total - lead;
+        const uint32_t lead = q0 < wtot ? q0 : wtot;
+        if (lead && lane == 0) *reinterpret_cast<uint64_t *>(dst) = pay[swzq8(0)];
+        const uint32_t rest = wtot - lead;
         const uint32_t npairs = rest >> 1;
-        for (uint32_t i = tid; i < npairs; i += kBlockThreads) {
-            const uint32_t k = lead + 2u * i;
+        for (uint32_t i = lane; i < npairs; i += 64u) {
+            const uint32_t q = lead + 2u * i;
             ulonglong2 v2;
-            v2.x = s_out[swzq8(k)];
-            v2.y = s_out[swzq8(k + 1u)];
-            *reinterpret_cast<ulonglong2 *>(dst + 8ull * k) = v2;
+            v2.x = pay[swzq8(q)];
+            v2.y = pay[swzq8(q + 1u)];
+            *reinterpret_cast<ulonglong2 *>(dst + 8ull * q) = v2;
         }
-        if ((rest & 1u) && tid == kBlockThreads - 1) {
-            const uint32_t k = chunk_total - 1u;
-            *reinterpret_cast<uint64_t *>(dst + 8ull * k) = s_out[swzq8(k)];
+        if ((rest & 1u) && lane == 63) {
+            const uint32_t q = wtot - 1u;
+            *reinterpret_cast<uint64_t *>(dst + 8ull * q) = pay[swzq8(q)];
         }
     } else {
-        for (uint32_t k = tid; k < chunk_total; k += kBlockThreads) store_u64_any(dst + 8ull * k, s_out[swzq8(k)]);
+        for (uint32_t q = lane; q < wtot; q += 64u) store_u64_any(dst + 8ull * q, pay[swzq8(q)]);
     }
+}
 
-    // ---- frame header and the I32 fields (dbde_util.cpp:140-146, 182-196) -------------------
+template <bool FAST_IN, bool ALIGNED_OUT>
+__global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
+    __shared__ __attribute__((aligned(16))) EncShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // The first workgroup to get here becomes the scanner: one of its waves runs the in-order
+    // scan, the others retire.  Being first to run, it is a running workgroup by construction.
+    const bool exp_static = (p.flags & 1u) != 0u;   // EXPERIMENT: static chunk assignment, no tickets
+    const uint32_t G = gridDim.x - 1u;              // workgroups that encode
     if (tid == 0) {
-        if (cf == 0u) {
-            const uint64_t index = p.indices ? p.indices[f] : p.first_index + f;
-            const uint64_t el = p.elapsed_ns ? p.elapsed_ns[f] : 0ull;
-            const uint64_t elbits = (uint64_t)__double_as_longlong(__ull2double_rn(el));   // trap T1: F64 on the wire
-            if (ALIGNED_OUT) {
-                uint32_t *h = reinterpret_cast<uint32_t *>(fb);
-                h[0] = 2u;
-                h[1] = (uint32_t)index; h[2] = (uint32_t)(index >> 32);
-                h[3] = (uint32_t)elbits; h[4] = (uint32_t)(elbits >> 32);
-                h[5] = p.T;
-                *reinterpret_cast<uint32_t *>(fb + 24 + p.T) = p.T;
-            } else {
-                store_u32_bytes(fb, 2u);
-                store_u32_bytes(fb + 4, (uint32_t)index); store_u32_bytes(fb + 8, (uint32_t)(index >> 32));
-                store_u32_bytes(fb + 12, (uint32_t)elbits); store_u32_bytes(fb + 16, (uint32_t)(elbits >> 32));
-                store_u32_bytes(fb + 20, p.T);
-                store_u32_bytes(fb + 24 + p.T, p.T);
+        sh.boot[0] = exp_static ? (blockIdx.x == 0u ? 0u : 1u) : atomicCAS(&p.ctrl[1], 0u, 1u);
+        sh.acc[0] = 0; sh.acc[1] = 0;
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(sh.boot[0]) == 0u) {
+        if (wave == 0) scanner_loop<ALIGNED_OUT>(p, lane);
+        return;
+    }
+    __syncthreads();   // sh.boot is reused below
+
+    // Two tickets in two dependent rounds: every workgroup takes its k-th ticket at about the
+    // same time, so chunks that are adjacent in the stream sit at the same pipeline position in
+    // different workgroups (and reach the scanner together).
+    if (tid == 0) {
+        uint32_t b0, b1;
+        if (exp_static) {
+            b0 = blockIdx.x - 1u; b1 = b0 + G;
+        } else {
+            b0 = atomicAdd(&p.ctrl[0], 1u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            b1 = atomicAdd(&p.ctrl[0], 1u + (b0 >> 31));
+        }
+        sh.boot[0] = b0; sh.boot[1] = b1;
+    }
+    __syncthreads();
+    ChunkRef cur = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[0]), tid);
+    ChunkRef nxt = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[1]), tid);
+    ChunkRef prev = chunk_ref(p, 0xFFFFFFFFu, tid);
+    uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
+    load_chunk<FAST_IN>(p, cur, r0a, r0b);
+    uint64_t *pay = sh.pay[wave];
+    uint32_t prev_meta = 0, prev_wbase = 0, prev_wtot = 0, prev_total = 0;
+
+    for (uint32_t it = 0;; it++) {
+        if (!cur.valid && !prev.valid) break;
+        const uint32_t par = it & 1u;
+
+        // ---- 1. mailbox of prev and the next ticket, before this iteration's loads --------------
+        if (tid == 0) {
+            uint32_t inf = 0, glob = 0, ok = 1u;
+            if (prev.valid) {
+                uint32_t inf_incl = 0, glob_incl = 0;
+                ok = wait_inc(p.state, prev.c, inf_incl, glob_incl) ? 1u : 0u;
+                inf = inf_incl - prev_total;
+                glob = glob_incl - prev_total;
+                if (!ok) atomicOr(p.sticky, 1u);
             }
-            if (p.frame_offsets) p.frame_offsets[f] = frame_base;
+            uint32_t tnew = 0xFFFFFFFFu;   // id of the chunk after nxt
+            if (nxt.valid) tnew = exp_static ? nxt.c + G : atomicAdd(&p.ctrl[0], 1u);
+            sh.lb[par][0] = inf;
+            sh.lb[par][1] = glob;
+            sh.lb[par][2] = ok;
+            sh.lb[par][3] = tnew;
         }
-        if (cf == p.chunks_per_frame - 1u) {
-            const uint32_t n64 = inf + chunk_total;
-            if (ALIGNED_OUT) *reinterpret_cast<uint32_t *>(fb + 28 + 2ull * p.T) = n64;
-            else store_u32_bytes(fb + 28 + 2ull * p.T, n64);
-            if (p.frame_bytes) p.frame_bytes[f] = meta + 8ull * n64;
+        // ---- 2. image loads of nxt (consumed when the pipeline rotates) --------------------------
+        load_chunk<FAST_IN>(p, nxt, r1a, r1b);
+
+        // ---- 3. statistics of cur (dbde_util.cpp:30-68), offsets inside the wave, AGG -------------
+        uint32_t mnA, mxA, mnB, mxB;
+        tile_minmax(r0a, mnA, mxA);
+        tile_minmax(r0b, mnB, mxB);
+        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
+        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
+        const uint32_t incl = wave_scan_incl(dA + dB);
+        const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
+        if (lane == 0) {
+            sh.tot[par][wave] = wtot;
+            // The last wave to get here publishes the chunk's AGG record at once: it never waits
+            // for a barrier or for the scanner.
+            const uint32_t old = atomicAdd(&sh.acc[par], (1u << 24) | wtot);
+            if ((old >> 24) == (uint32_t)(kEncWaves - 1)) {
+                sh.acc[par] = 0;   // next used two iterations from now
+                if (cur.valid) {
+                    const uint32_t total = (old & 0xFFFFFFu) + wtot;
+                    __hip_atomic_store(&p.state[cur.c], kStAgg | (u64a)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
+        __syncthreads();   // ---- 4. the one workgroup barrier ----
+        const uint32_t inf = sh.lb[par][0], glob = sh.lb[par][1], lb_ok = sh.lb[par][2];
+        const uint32_t next_id = __builtin_amdgcn_readfirstlane(sh.lb[par][3]);
+        if (!lb_ok) return;
+        uint32_t wbase = 0, cur_total = 0;
+#pragma unroll
+        for (int k = 0; k < kEncWaves; k++) {
+            const uint32_t tk = sh.tot[par][k];
+            wbase += k < wave ? tk : 0u;
+            cur_total += tk;
+        }
+
+        // ---- 5. prev: LDS -> global; cur: pack over it (wave-private region) -----------------------
+        if (prev.valid) store_wave_part<ALIGNED_OUT>(p, prev, prev_meta, prev_wbase, prev_wtot, inf, glob, pay, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (wtot != 0u) {
+            const uint32_t offA = incl - (dA + dB), offB = offA + dA;
+            const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
+            if (all8) {
+                if (cur.hasA) pack_tile_d8(r0a, mnA, pay, offA);
+                if (cur.hasB) pack_tile_d8(r0b, mnB, pay, offB);
+            } else {
+                pack_tile(r0a, mnA, dA, pay, offA);
+                pack_tile(r0b, mnB, dB, pay, offB);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- rotate the pipeline -------------------------------------------------------------------
+        prev = cur;
+        prev_meta = dA | (dB << 8) | (mnA << 16) | (mnB << 24);
+        prev_wbase = wbase;
+        prev_wtot = wtot;
+        prev_total = cur_total;
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { r0a[i] = r1a[i]; r0b[i] = r1b[i]; }
+        nxt = chunk_ref(p, next_id, tid);
     }
 }
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
-    dim3 grid(p.n_chunks), block(kBlockThreads);
+    dim3 block(kEncThreads);
+    dim3 grid((p.n_chunks < p.grid_blocks ? p.n_chunks : p.grid_blocks) + ((p.flags & 1u) ? 0u : 1u));   // + the scanner
     if (fast_in && aligned_out) hipLaunchKernelGGL((encode_kernel<true, true>), grid, block, 0, s, p);
     else if (fast_in) hipLaunchKernelGGL((encode_kernel<true, false>), grid, block, 0, s, p);
     else if (aligned_out) hipLaunchKernelGGL((encode_kernel<false, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((encode_kernel<false, false>), grid, block, 0, s, p);
     return hipGetLastError();
+}
+
+// Resident workgroups per CU of the encoder (occupancy query; LDS- and VGPR-bound).
+int encode_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, encode_kernel<true, true>, kEncThreads, 0) != hipSuccess || n < 1)
+        n = 1;
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------

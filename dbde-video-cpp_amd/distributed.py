@@ -1,0 +1,65 @@
+"""Frame-level data parallelism for the DBDE path.
+
+Frames are independent (no inter-frame state in dbde_pack_image / dbde_unpack_image), so the
+path shards by CONTIGUOUS FRAME BLOCKS: rank g of G owns frames [g*N/G, (g+1)*N/G).  Each
+rank's compressed output is then one contiguous, in-order segment of the final stream and
+there is no collective on the encode/decode data path.  The only exchange step is the
+variable-length gather of the compressed byte stream to a root (RCCL has no gatherv):
+  1. all_gather of the per-rank byte counts,
+  2. exclusive scan -> displacement of each rank's segment,
+  3. one grouped isend / irecv per peer straight into the root's buffer at its displacement.
+Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on device tensors,
+"gloo" on CPU tensors (tests/test_distributed_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(n_frames, rank, world):
+    """Contiguous block of frame indices [lo, hi) owned by `rank`."""
+    lo = (n_frames * rank) // world
+    hi = (n_frames * (rank + 1)) // world
+    return lo, hi
+
+
+def gather_stream(segment, nbytes, dst=0, group=None, out=None):
+    """Gathers every rank's first `nbytes` bytes of `segment` (uint8, 1-D) to rank `dst`, in rank
+    order.  Returns (stream, sizes) on dst -- `stream` holds sum(sizes) bytes -- and (None, sizes)
+    elsewhere.  `out` may supply the destination buffer on dst (>= sum(sizes) bytes)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = segment.device
+    mine = torch.tensor([int(nbytes)], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, mine, group=group)
+    sizes = [int(s.item()) for s in all_sizes]
+    if rank == dst:
+        total = sum(sizes)
+        if out is None:
+            out = torch.empty(total, dtype=torch.uint8, device=dev)
+        assert out.numel() >= total
+        at, ops = 0, []
+        for r in range(world):
+            if r == rank:
+                out[at:at + sizes[r]].copy_(segment[:sizes[r]])
+            elif sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[at:at + sizes[r]], r, group))
+            at += sizes[r]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return out[:total], sizes
+    if sizes[rank]:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, segment[:sizes[rank]], dst, group)]):
+            w.wait()
+    return None, sizes
+
+
+def frame_offsets_from_sizes(per_rank_frame_bytes):
+    """Root-side frame index of the gathered stream: list (per rank) of per-frame byte counts ->
+    flat list of frame offsets relative to the first frame (exclusive scan)."""
+    offs, at = [], 0
+    for sizes in per_rank_frame_bytes:
+        for s in sizes:
+            offs.append(at)
+            at += int(s)
+    return offs, at

@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the N > 1 path -- frame-block sharding and the variable-length
+gather of the compressed stream -- with the oracle standing in for the per-rank encoder
+(the GPU encoder has no CPU form; what is tested here is the host logic around it)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+W, H, N = 37, 21, 11      # odd sizes, uneven split over 2 ranks
+SEED = 0xDBDE2016
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (HERE, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dbde_video_cpp_amd as dv
+    from dbde_video_cpp_amd import distributed as dd
+    from oracle_ffi import Oracle
+    ora = Oracle()
+    lo, hi = dd.shard_frames(N, rank, world)
+    frames = [ora.pack_frame(f, ora.synth_frame(1, SEED, f, W, H), W, H) for f in range(lo, hi)]
+    seg = torch.from_numpy(np.concatenate(frames + [np.zeros(16, np.uint8)]))
+    nbytes = sum(len(f) for f in frames)
+    stream, sizes = dd.gather_stream(seg, nbytes, dst=0)
+    if rank == 0:
+        assert sum(sizes) == stream.numel()
+        # the gathered stream is exactly what one rank would have produced for all N frames
+        want = np.concatenate([ora.pack_frame(f, ora.synth_frame(1, SEED, f, W, H), W, H) for f in range(N)])
+        ok = stream.numpy().tobytes() == want.tobytes()
+        # and a full file = video header + stream parses frame by frame
+        body = stream.numpy()
+        at, n = 0, 0
+        while at < len(body):
+            adv, fh, img = ora.unpack_frame(body[at:], W, H)
+            ok = ok and fh == (2, n, 0) and (img == ora.synth_frame(1, SEED, n, W, H)).all()
+            at += adv
+            n += 1
+        q.put(bool(ok and n == N))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_frames_partition():
+    sys.path.insert(0, ROOT)
+    from dbde_video_cpp_amd import distributed as dd
+    for n in (0, 1, 7, 64, 10000):
+        for world in (1, 2, 3, 8):
+            blocks = [dd.shard_frames(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
+    offs, total = dd.frame_offsets_from_sizes([[10, 20], [5], [], [7, 7]])
+    assert offs == [0, 10, 30, 35, 42] and total == 49
+
+
+def test_gather_stream_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True

@@ -30,14 +30,14 @@ struct EncParams {
     const uint64_t *elapsed_ns;    // optional [n_frames]
     uint64_t first_index;
     unsigned long long *state;     // [n_chunks] look-back records, zeroed before the launch
-    uint32_t *ctrl;                // [0] ticket counter; zeroed before the launch
+    uint32_t *ctrl;                // [1] scanner claim, [2] arrivals + tickets, [3] claim mode; zeroed before the launch
     uint32_t *sticky;              // context-wide failure word, OR-ed on look-back time-out
     uint64_t slot_stride;          // 0 = frames concatenated
     uint64_t frame_pixels;         // W*H
     int W, H;
     uint32_t w, h, T;              // tiles across, down, total
     uint32_t chunks_per_frame, n_chunks;
-    uint32_t flags;                // reserved for tuning experiments
+    uint32_t flags;                // bit 0: force ticket mode (A/B measurements)
     uint32_t grid_blocks;          // resident workgroups of the persistent encoder
 };
 

@@ -440,39 +440,49 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
 
     // The first workgroup to get here becomes the scanner: one of its waves runs the in-order
     // scan, the others retire.  Being first to run, it is a running workgroup by construction.
-    const bool exp_static = (p.flags & 1u) != 0u;   // EXPERIMENT: static chunk assignment, no tickets
     const uint32_t G = gridDim.x - 1u;              // workgroups that encode
     if (tid == 0) {
-        sh.boot[0] = exp_static ? (blockIdx.x == 0u ? 0u : 1u) : atomicCAS(&p.ctrl[1], 0u, 1u);
+        const uint32_t is_scanner = atomicCAS(&p.ctrl[1], 0u, 1u) == 0u ? 1u : 0u;
+        sh.boot[1] = is_scanner;
+        // every encoding workgroup's FIRST chunk is its arrival rank: dense, in start order
+        sh.boot[0] = is_scanner ? 0u : atomicAdd(&p.ctrl[2], 1u);
         sh.acc[0] = 0; sh.acc[1] = 0;
     }
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(sh.boot[0]) == 0u) {
+    if (__builtin_amdgcn_readfirstlane(sh.boot[1]) != 0u) {
         if (wave == 0) scanner_loop<ALIGNED_OUT>(p, lane);
         return;
     }
+    const uint32_t rank = __builtin_amdgcn_readfirstlane(sh.boot[0]);
+    ChunkRef cur = chunk_ref(p, rank, tid);
+    uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
+    load_chunk<FAST_IN>(p, cur, r0a, r0b);          // in flight while the mode is agreed below
     __syncthreads();   // sh.boot is reused below
 
-    // Two tickets in two dependent rounds: every workgroup takes its k-th ticket at about the
-    // same time, so chunks that are adjacent in the stream sit at the same pipeline position in
-    // different workgroups (and reach the scanner together).
+    // How later chunks are claimed.  STATIC (chunk = rank + k*G, no atomics) is only safe when
+    // every one of the G encoding workgroups is running at the same time; that is proven, not
+    // assumed: all G have arrived before anyone left.  One CAS makes the decision for the whole
+    // launch; if the arrivals do not complete within ~20 us (oversubscribed device, occupancy
+    // over-estimated), the decision is TICKETS (the arrival counter keeps counting: chunk ids are
+    // dense in draw order), which needs nothing but running workgroups.  (A single-address ticket per chunk costs 6-13 % at full speed.)
     if (tid == 0) {
-        uint32_t b0, b1;
-        if (exp_static) {
-            b0 = blockIdx.x - 1u; b1 = b0 + G;
-        } else {
-            b0 = atomicAdd(&p.ctrl[0], 1u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            b1 = atomicAdd(&p.ctrl[0], 1u + (b0 >> 31));
+        uint32_t mode = 0;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+            mode = __hip_atomic_load(&p.ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mode) break;
+            const uint32_t arrived = __hip_atomic_load(&p.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived >= G && !(p.flags & 1u)) atomicCAS(&p.ctrl[3], 0u, 1u);
+            else if ((p.flags & 1u) || wall_clock64() - t0 > 2000ull) atomicCAS(&p.ctrl[3], 0u, 2u);
+            else __builtin_amdgcn_s_sleep(2);
         }
-        sh.boot[0] = b0; sh.boot[1] = b1;
+        sh.boot[1] = mode;
+        sh.boot[0] = mode == 1u ? rank + G : atomicAdd(&p.ctrl[2], 1u);   // tickets continue the arrival counter: ids stay dense
     }
     __syncthreads();
-    ChunkRef cur = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[0]), tid);
-    ChunkRef nxt = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[1]), tid);
+    const bool static_mode = __builtin_amdgcn_readfirstlane(sh.boot[1]) == 1u;
+    ChunkRef nxt = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[0]), tid);
     ChunkRef prev = chunk_ref(p, 0xFFFFFFFFu, tid);
-    uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-    load_chunk<FAST_IN>(p, cur, r0a, r0b);
     uint64_t *pay = sh.pay[wave];
     uint32_t prev_meta = 0, prev_wbase = 0, prev_wtot = 0, prev_total = 0;
 
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
                 if (!ok) atomicOr(p.sticky, 1u);
             }
             uint32_t tnew = 0xFFFFFFFFu;   // id of the chunk after nxt
-            if (nxt.valid) tnew = exp_static ? nxt.c + G : atomicAdd(&p.ctrl[0], 1u);
+            if (nxt.valid) tnew = static_mode ? nxt.c + G : atomicAdd(&p.ctrl[2], 1u);
             sh.lb[par][0] = inf;
             sh.lb[par][1] = glob;
             sh.lb[par][2] = ok;
@@ -566,7 +576,8 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
     dim3 block(kEncThreads);
-    dim3 grid((p.n_chunks < p.grid_blocks ? p.n_chunks : p.grid_blocks) + ((p.flags & 1u) ? 0u : 1u));   // + the scanner
+    // resident capacity, scanner included (so that all encoding workgroups can be co-resident)
+    dim3 grid(p.n_chunks + 1u < p.grid_blocks ? p.n_chunks + 1u : p.grid_blocks);
     if (fast_in && aligned_out) hipLaunchKernelGGL((encode_kernel<true, true>), grid, block, 0, s, p);
     else if (fast_in) hipLaunchKernelGGL((encode_kernel<true, false>), grid, block, 0, s, p);
     else if (aligned_out) hipLaunchKernelGGL((encode_kernel<false, true>), grid, block, 0, s, p);

@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--content", default="noise8", choices=["noise8", "mixed", "smooth", "flat"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--slot", action="store_true", help="one fixed-stride slot per frame instead of a concatenated stream")
+    ap.add_argument("--no-check", action="store_true", help="(experiments) skip the round-trip parity gate")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,7 +96,8 @@ def main():
 
     # ---- inputs resident in HBM before the timed region ------------------------------------
     imgs = codec.synth_frames(args.content, SEED, rank * B, B, W, H)
-    buf, lead, cap = codec.alloc_stream(W, H, B)
+    slot = ((dv.max_frame_bytes(W, H) + 255) // 256) * 256 if args.slot else 0
+    buf, lead, cap = codec.alloc_stream(W, H, B, slot_stride=slot)
     out = torch.empty_like(imgs)
     offs = torch.empty(B, dtype=torch.int64, device=dev)
     sizes = torch.empty(B, dtype=torch.int64, device=dev)
@@ -102,7 +105,7 @@ def main():
     stream_cap = cap
 
     def step():
-        codec.encode_frames(imgs, W, H, B, buf, lead, cap, first_index=rank * B, offsets=offs, nbytes=sizes)
+        codec.encode_frames(imgs, W, H, B, buf, lead, cap, first_index=rank * B, offsets=offs, nbytes=sizes, slot_stride=slot)
         codec.decode_frames(buf, lead, stream_cap, offs, W, H, B, images=out, results=res)
 
     def fence():
@@ -115,7 +118,7 @@ def main():
         step()
     codec.sync()
     # parity gate on the measured configuration: round trip identical, sizes consistent
-    assert torch.equal(out, imgs), "round trip mismatch"
+    assert args.no_check or torch.equal(out, imgs), "round trip mismatch"
     s_h = sizes.cpu().numpy()
     packed_bytes = int(s_h.sum())
 

@@ -254,8 +254,13 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         ctx->lb_bytes = have;
     }
     const size_t zero_bytes = lb_need;
+    // Frame-wise kernel: slot layout and enough frames to give every resident workgroup its own
+    // ($DBDE_HIP_FRAMEWISE_MIN overrides the threshold; 0 disables).
+    uint32_t fw_min = ctx->enc_grid / 2;
+    if (const char *e = getenv("DBDE_HIP_FRAMEWISE_MIN")) fw_min = (uint32_t)strtoul(e, nullptr, 0);
+    const bool framewise = slot_stride != 0 && fw_min != 0 && (uint32_t)n_frames >= fw_min;
     span_begin(ctx, 0);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, zero_bytes, ctx->stream));
+    if (!framewise) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, zero_bytes, ctx->stream));
 
     EncParams p;
     p.images = d_images;
@@ -282,7 +287,8 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     const bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);
-    HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
+    if (framewise) HIP_TRY(ctx, launch_encode_framewise(p, fast_in, aligned_out, ctx->stream));
+    else HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;
 }

@@ -574,6 +574,90 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// ENCODE, frame-wise form: one workgroup owns whole frames (slot layout, many frames)
+// ---------------------------------------------------------------------------------------
+// With one output slot per frame (the reference's own semantics: dbde_pack_frame packs each
+// frame into its own target) frames do not depend on each other.  When the batch has at least
+// as many frames as the device holds workgroups, a workgroup simply walks its frames chunk by
+// chunk and carries the payload offset in a register: no tickets, no records, no scanner, no
+// waiting on any other workgroup (so nothing to prove about residency either).  Same per-chunk
+// pipeline as above: nxt's image loads in flight while cur is reduced, packed into the wave's
+// LDS region and stored; one workgroup barrier per chunk (the wave totals).
+struct EncSharedFW {
+    uint64_t pay[kEncWaves][kWaveWords];
+    uint32_t tot[2][kEncWaves];
+};
+
+template <bool FAST_IN, bool ALIGNED_OUT>
+__global__ __launch_bounds__(kEncThreads) void encode_framewise_kernel(EncParams p) {
+    __shared__ __attribute__((aligned(16))) EncSharedFW sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t cpf = p.chunks_per_frame;
+    const uint32_t n_frames = p.n_chunks / cpf;
+    uint64_t *pay = sh.pay[wave];
+
+    uint32_t f = blockIdx.x, cf = 0;
+    if (f >= n_frames) return;
+    ChunkRef cur = chunk_ref(p, f * cpf, tid);
+    uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
+    load_chunk<FAST_IN>(p, cur, r0a, r0b);
+    uint32_t inf = 0;   // payload words of this frame before cur
+
+    for (uint32_t it = 0; cur.valid; it++) {
+        const uint32_t par = it & 1u;
+        // next chunk: same frame, or the first chunk of this workgroup's next frame
+        uint32_t nf = f, ncf = cf + 1u;
+        if (ncf == cpf) { ncf = 0; nf = f + gridDim.x; }
+        const ChunkRef nxt = chunk_ref(p, nf < n_frames ? nf * cpf + ncf : 0xFFFFFFFFu, tid);
+        load_chunk<FAST_IN>(p, nxt, r1a, r1b);
+
+        // statistics (dbde_util.cpp:30-68) and offsets inside the wave
+        uint32_t mnA, mxA, mnB, mxB;
+        tile_minmax(r0a, mnA, mxA);
+        tile_minmax(r0b, mnB, mxB);
+        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
+        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
+        const uint32_t incl = wave_scan_incl(dA + dB);
+        const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
+        if (lane == 0) sh.tot[par][wave] = wtot;
+        __syncthreads();
+        uint32_t wbase = 0, cur_total = 0;
+#pragma unroll
+        for (int k = 0; k < kEncWaves; k++) {
+            const uint32_t tk = sh.tot[par][k];
+            wbase += k < wave ? tk : 0u;
+            cur_total += tk;
+        }
+
+        // pack into the wave's LDS region, then LDS -> global (16 B per lane)
+        if (wtot != 0u) {
+            const uint32_t offA = incl - (dA + dB), offB = offA + dA;
+            const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
+            if (all8) {
+                if (cur.hasA) pack_tile_d8(r0a, mnA, pay, offA);
+                if (cur.hasB) pack_tile_d8(r0b, mnB, pay, offB);
+            } else {
+                pack_tile(r0a, mnA, dA, pay, offA);
+                pack_tile(r0b, mnB, dB, pay, offB);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        store_wave_part<ALIGNED_OUT>(p, cur, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, inf, pay, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0 && (cf == 0u || cf == cpf - 1u))
+            scanner_frame_fields<ALIGNED_OUT>(p, f, cf, inf + cur_total, 0u);
+
+        inf = ncf == 0u ? 0u : inf + cur_total;
+        f = nf; cf = ncf;
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { r0a[i] = r1a[i]; r0b[i] = r1b[i]; }
+    }
+}
+
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
     dim3 block(kEncThreads);
     // resident capacity, scanner included (so that all encoding workgroups can be co-resident)
@@ -582,6 +666,16 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
     else if (fast_in) hipLaunchKernelGGL((encode_kernel<true, false>), grid, block, 0, s, p);
     else if (aligned_out) hipLaunchKernelGGL((encode_kernel<false, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((encode_kernel<false, false>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_framewise(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
+    const uint32_t n_frames = p.n_chunks / p.chunks_per_frame;
+    dim3 block(kEncThreads), grid(n_frames < p.grid_blocks ? n_frames : p.grid_blocks);
+    if (fast_in && aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<true, true>), grid, block, 0, s, p);
+    else if (fast_in) hipLaunchKernelGGL((encode_framewise_kernel<true, false>), grid, block, 0, s, p);
+    else if (aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((encode_framewise_kernel<false, false>), grid, block, 0, s, p);
     return hipGetLastError();
 }
 

@@ -136,10 +136,17 @@ def test_batch_encode_matches_oracle(codec, oracle, W, H, n, mode):
     import torch
     imgs = codec.synth_frames(mode, SEED, 100, n, W, H)
     imgs_h = imgs.cpu().numpy()
-    for slot in (0, ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256):
+    import os
+    slot_bytes = ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
+    # layouts: concatenated; one slot per frame (scanner path); one slot per frame, frame-wise kernel
+    for slot, framewise in ((0, False), (slot_bytes, False), (slot_bytes, True)):
         for misalign in (0, 3):
-            frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=100,
-                                                          slot_stride=slot, misalign=misalign)
+            os.environ["DBDE_HIP_FRAMEWISE_MIN"] = "1" if framewise else "0"
+            try:
+                frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=100,
+                                                              slot_stride=slot, misalign=misalign)
+            finally:
+                os.environ.pop("DBDE_HIP_FRAMEWISE_MIN", None)
             for f in range(n):
                 want = oracle.pack_frame(100 + f, imgs_h[f], W, H)
                 assert frames[f].tobytes() == want.tobytes(), (W, H, mode, slot, misalign, f)
@@ -271,4 +278,27 @@ def test_large_batch_properties(codec, oracle):
         codec.sync()
         assert torch.equal(back, imgs)
         assert all(r == (2, f, 0, int(s[f])) for f, r in enumerate(codec.parse_results(res)))
+        del imgs, buf, back
+
+
+def test_framewise_many_frames(codec, oracle):
+    """Slot layout with more frames than resident workgroups: the frame-wise kernel (a workgroup
+    owns whole frames, several in a row), against the oracle and round trip."""
+    import torch
+    for (W, H, n, mode) in [(1024, 768, 1300, "mixed"), (333, 200, 700, "smooth"), (2048, 2048, 520, "noise8")]:
+        imgs = codec.synth_frames(mode, SEED, 7, n, W, H)
+        slot = ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
+        buf, lead, cap = codec.alloc_stream(W, H, n, slot_stride=slot)
+        offs, sizes = codec.encode_frames(imgs, W, H, n, buf, lead, cap, first_index=7, slot_stride=slot)
+        codec.sync()
+        o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+        assert (o == np.arange(n) * slot).all()
+        host = buf.cpu().numpy()
+        for f in (0, 1, n // 2, n - 2, n - 1):
+            want = oracle.pack_frame(7 + f, oracle.synth_frame(MODES[mode], SEED, 7 + f, W, H), W, H)
+            assert host[lead + o[f]: lead + o[f] + s[f]].tobytes() == want.tobytes(), (W, H, mode, f)
+        back, res = codec.decode_frames(buf, lead, cap, offs, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs)
+        assert all(r == (2, 7 + f, 0, int(s[f])) for f, r in enumerate(codec.parse_results(res)))
         del imgs, buf, back

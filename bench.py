@@ -4,8 +4,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--content noise8|mixed]
 
 One step = one pass of the hot path over one batch: encode B distinct synthetic 4096x3072 U8
-frames (resident in HBM) into a concatenated DBDE stream, then decode that stream back to
-images.  B*W*H is far beyond the 256 MiB Infinity Cache, so every step streams from HBM.
+frames (resident in HBM) into DBDE frames, then decode them back to images.  Default layout:
+one fixed-stride slot per frame -- the reference's own semantics, dbde_pack_frame packs each
+frame into its own target -- which lets the encoder give every workgroup whole frames;
+--concat writes one concatenated stream instead (a ready .dbde body; chunk offsets then come
+from an in-launch scan).  B*W*H is far beyond the 256 MiB Infinity Cache, so every step
+streams from HBM.  Default B = 1024 (BASELINE config 5 gives each GPU 1250 frames).
 N > 1: launched by torch.distributed.run, one rank per GPU; frames are sharded by blocks
 (rank g owns frames [g*B, (g+1)*B)), no collective on the data path (weak scaling).  The
 RCCL gather of the compressed stream to rank 0 is run and timed separately ("gather").
@@ -69,11 +73,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per step per GPU")
     ap.add_argument("--content", default="noise8", choices=["noise8", "mixed", "smooth", "flat"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--slot", action="store_true", help="one fixed-stride slot per frame instead of a concatenated stream")
+    ap.add_argument("--concat", action="store_true", help="one concatenated stream instead of one slot per frame")
     ap.add_argument("--no-check", action="store_true", help="(experiments) skip the round-trip parity gate")
     args = ap.parse_args()
 
@@ -96,7 +100,7 @@ def main():
 
     # ---- inputs resident in HBM before the timed region ------------------------------------
     imgs = codec.synth_frames(args.content, SEED, rank * B, B, W, H)
-    slot = ((dv.max_frame_bytes(W, H) + 255) // 256) * 256 if args.slot else 0
+    slot = 0 if args.concat else ((dv.max_frame_bytes(W, H) + 255) // 256) * 256
     buf, lead, cap = codec.alloc_stream(W, H, B, slot_stride=slot)
     out = torch.empty_like(imgs)
     offs = torch.empty(B, dtype=torch.int64, device=dev)
@@ -149,7 +153,8 @@ def main():
     alg = raw + packed_bytes                      # encode reads raw, writes packed; decode the reverse
     enc_gbps = alg / (enc_ms * 1e-3) / 1e9
     dec_gbps = alg / (dec_ms * 1e-3) / 1e9
-    dom = ("dbde::encode_kernel", enc_ms, enc_gbps) if enc_ms >= dec_ms else ("dbde::decode_kernel", dec_ms, dec_gbps)
+    enc_name = "dbde::encode_framewise_kernel" if (slot and B >= 256) else "dbde::encode_kernel"
+    dom = (enc_name, enc_ms, enc_gbps) if enc_ms >= dec_ms else ("dbde::decode_kernel", dec_ms, dec_gbps)
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[2], 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(dom[2] / HBM_PEAK_GBPS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": alg, "launch_ms": round(dom[1], 4),
@@ -160,7 +165,9 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(traffic_file):
         try:
-            roofline["traffic"] = json.load(open(traffic_file)).get(args.content, {}).get(dom[0])
+            t = json.load(open(traffic_file)).get(args.content, {})
+            # per-launch HBM bytes from the rocprofv3 PMC passes (profiles/*_summary.txt), same batch
+            roofline["traffic"] = t.get(dom[0]) if t.get("frames_per_launch") == B else None
         except Exception:
             pass
 
@@ -194,9 +201,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: 4096x3072 U8 frames, {args.content}, "
+            "config": {"workload": f"BASELINE configs[1] shape: 4096x3072 U8 frames, {args.content}, "
                                    f"{B} distinct frames per step per GPU, device-resident in and out, "
-                                   "concatenated stream", "frames_per_step_per_gpu": B, "content": args.content,
+                                   + ("one concatenated stream" if args.concat else "one slot per frame"),
+                       "frames_per_step_per_gpu": B, "content": args.content,
+                       "layout": "concat" if args.concat else "slots",
                        "packed_over_raw": round(packed_bytes / raw, 4), "parallelism": f"frames sharded x{world}"},
             "roofline": roofline,
         }

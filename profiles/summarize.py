@@ -46,8 +46,9 @@ def main():
             for c, v in acc[k].items():
                 avg = sum(v) / len(v)
                 out.append(f"{k[:70]:70s} {c:24s} {avg:18.1f} {len(v):6d}")
-                if c in ("FETCH_SIZE", "WRITE_SIZE") and ("encode_kernel" in k or "decode_kernel" in k):
-                    name = "dbde::encode_kernel" if "encode_kernel" in k else "dbde::decode_kernel"
+                if c in ("FETCH_SIZE", "WRITE_SIZE") and ("dbde::encode_" in k or "dbde::decode_kernel" in k):
+                    name = ("dbde::encode_framewise_kernel" if "encode_framewise" in k else
+                            "dbde::encode_kernel" if "encode_kernel" in k else "dbde::decode_kernel")
                     traffic.setdefault(name, {})[c] = avg
     for name, t in traffic.items():
         if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
@@ -61,6 +62,10 @@ def main():
     tf = os.path.join(here, "hbm_traffic.json")
     cur = json.load(open(tf)) if os.path.exists(tf) else {}
     cur[content] = {k: int(v["bytes"]) for k, v in traffic.items() if "bytes" in v}
+    # frames per launch of the profiled run: raw image bytes written by the decoder / frame size
+    dec = traffic.get("dbde::decode_kernel", {})
+    if "WRITE_SIZE" in dec:
+        cur[content]["frames_per_launch"] = int(round(dec["WRITE_SIZE"] * 1024 / (4096 * 3072)))
     json.dump(cur, open(tf, "w"), indent=1)
     print("\n".join(out))
 

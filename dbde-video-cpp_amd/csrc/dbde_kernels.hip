@@ -19,7 +19,13 @@
 
 #include "dbde_bits.h"
 
+#ifndef DBDE_NT
+#define DBDE_NT 1   // non-temporal hint on the streamed-once traffic (pixels, payload, decoded images)
+#endif
+
 namespace dbde {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // native vector for the nontemporal builtins
 
 typedef unsigned long long u64a;   // type of the look-back records
 
@@ -336,9 +342,10 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
             for (int r = 0; r < 8; r++) {
                 int yy = 8 * (int)ty + r;
                 yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
-                const uint4 q = *reinterpret_cast<const uint4 *>(base + (size_t)yy * (size_t)p.W);
-                va[2 * r] = q.x; va[2 * r + 1] = q.y;
-                vb[2 * r] = q.z; vb[2 * r + 1] = q.w;
+                const u32x4_t *src = reinterpret_cast<const u32x4_t *>(base + (size_t)yy * (size_t)p.W);
+                const u32x4_t q = DBDE_NT ? __builtin_nontemporal_load(src) : *src;
+                va[2 * r] = q[0]; va[2 * r + 1] = q[1];
+                vb[2 * r] = q[2]; vb[2 * r + 1] = q[3];
             }
         }
     } else {
@@ -422,7 +429,13 @@ __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkR
             ulonglong2 v2;
             v2.x = pay[swzq8(q)];
             v2.y = pay[swzq8(q + 1u)];
-            *reinterpret_cast<ulonglong2 *>(dst + 8ull * q) = v2;
+            if (DBDE_NT) {
+                u32x4_t o;
+                o[0] = (uint32_t)v2.x; o[1] = (uint32_t)(v2.x >> 32); o[2] = (uint32_t)v2.y; o[3] = (uint32_t)(v2.y >> 32);
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(dst + 8ull * q));
+            } else {
+                *reinterpret_cast<ulonglong2 *>(dst + 8ull * q) = v2;
+            }
         }
         if ((rest & 1u) && lane == 63) {
             const uint32_t q = wtot - 1u;
@@ -917,7 +930,7 @@ __global__ __launch_bounds__(kBlockThreads) void decode_kernel(DecParams p) {
             const uint32_t wave_slot0 = (uint32_t)j * kBlockThreads + (uint32_t)wave * 64u;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(asrc + 16ull * src_slot),
-                (__attribute__((address_space(3))) void *)(&s_in[2u * wave_slot0]), 16, 0, 0);
+                (__attribute__((address_space(3))) void *)(&s_in[2u * wave_slot0]), 16, 0, DBDE_NT ? 2 : 0);
         }
     }
     uint32_t dA = 0, dB = 0, mA = 0, mB = 0;
@@ -943,7 +956,13 @@ __global__ __launch_bounds__(kBlockThreads) void decode_kernel(DecParams p) {
                 if (yy < p.H) {
                     uint4 q;
                     q.x = va[2 * r]; q.y = va[2 * r + 1]; q.z = vb[2 * r]; q.w = vb[2 * r + 1];
-                    *reinterpret_cast<uint4 *>(base + (size_t)yy * (size_t)p.W) = q;
+                    if (DBDE_NT) {
+                        u32x4_t o;
+                        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W));
+                    } else {
+                        *reinterpret_cast<uint4 *>(base + (size_t)yy * (size_t)p.W) = q;
+                    }
                 }
             }
         }

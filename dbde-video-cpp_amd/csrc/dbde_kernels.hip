@@ -19,6 +19,9 @@
 
 #include "dbde_bits.h"
 
+#ifndef DBDE_PACK2
+#define DBDE_PACK2 1   // straight-line two-tile pack in the frame-wise encoder
+#endif
 #ifndef DBDE_NT
 #define DBDE_NT 1   // non-temporal hint on the streamed-once traffic (pixels, payload, decoded images)
 #endif
@@ -381,6 +384,37 @@ __device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, 
     }
 }
 
+// Both tiles of the lane advance together, straight-line (no exec-mask branches): a row that does
+// not complete a word writes to the lane's trash word instead, so the scheduler can interleave the
+// two dependency chains.
+__device__ __forceinline__ void pack_two_tiles(const uint32_t (&va)[16], uint32_t mnA, uint32_t dA, uint32_t qA,
+                                               const uint32_t (&vb)[16], uint32_t mnB, uint32_t dB, uint32_t qB,
+                                               uint64_t *pay, uint32_t trash) {
+    const uint32_t mA = mnA * 0x01010101u, mB = mnB * 0x01010101u;
+    const uint32_t wA = 1u | ((1u << dA) << 8), wB = 1u | ((1u << dB) << 8);
+    const bool a8 = dA >= 8u, b8 = dB >= 8u;
+    const uint32_t nbA = 8u * dA, nbB = 8u * dB;
+    uint64_t accA = 0, accB = 0;
+    uint32_t fillA = 0, fillB = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint64_t rowA = pack_row_dot(va[2 * r] - mA, va[2 * r + 1] - mA, dA, wA, wA << 16, a8);
+        const uint64_t rowB = pack_row_dot(vb[2 * r] - mB, vb[2 * r + 1] - mB, dB, wB, wB << 16, b8);
+        const uint64_t wordA = accA | (rowA << fillA), wordB = accB | (rowB << fillB);
+        const uint32_t nfA = fillA + nbA, nfB = fillB + nbB;
+        const bool emitA = nfA >= 64u, emitB = nfB >= 64u;
+        const uint64_t spillA = (rowA >> 1) >> (63u - fillA), spillB = (rowB >> 1) >> (63u - fillB);
+        accA = emitA ? spillA : wordA;
+        accB = emitB ? spillB : wordB;
+        fillA = nfA & 63u;
+        fillB = nfB & 63u;
+        pay[emitA ? swzq8(qA) : trash] = wordA;
+        pay[emitB ? swzq8(qB) : trash] = wordB;
+        qA += emitA ? 1u : 0u;
+        qB += emitB ? 1u : 0u;
+    }
+}
+
 // Depth 8 everywhere in the wave: the payload is the min-subtracted bytes, row by row.
 __device__ __forceinline__ void pack_tile_d8(const uint32_t (&v)[16], uint32_t mn, uint64_t *pay, uint32_t q) {
     const uint32_t m4 = mn * 0x01010101u;
@@ -598,7 +632,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
 // pipeline as above: nxt's image loads in flight while cur is reduced, packed into the wave's
 // LDS region and stored; one workgroup barrier per chunk (the wave totals).
 struct EncSharedFW {
-    uint64_t pay[kEncWaves][kWaveWords];
+    uint64_t pay[kEncWaves][kWaveWords + 64];   // + one trash word per lane (pack_two_tiles)
     uint32_t tot[2][kEncWaves];
 };
 
@@ -651,8 +685,12 @@ __global__ __launch_bounds__(kEncThreads) void encode_framewise_kernel(EncParams
                 if (cur.hasA) pack_tile_d8(r0a, mnA, pay, offA);
                 if (cur.hasB) pack_tile_d8(r0b, mnB, pay, offB);
             } else {
+#if DBDE_PACK2
+                pack_two_tiles(r0a, mnA, dA, offA, r0b, mnB, dB, offB, pay, kWaveWords + (uint32_t)lane);
+#else
                 pack_tile(r0a, mnA, dA, pay, offA);
                 pack_tile(r0b, mnB, dB, pay, offB);
+#endif
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -287,7 +287,14 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     const bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);
-    if (framewise) HIP_TRY(ctx, launch_encode_framewise(p, fast_in, aligned_out, ctx->stream));
+    if (framewise) {
+        int fw_waves = 8;
+        if (const char *e = getenv("DBDE_HIP_FRAMEWISE_WAVES")) fw_waves = atoi(e) == 4 ? 4 : 8;
+        const uint32_t ct = (uint32_t)fw_waves * 128u;
+        p.chunks_per_frame = (g.T + ct - 1) / ct;
+        p.n_chunks = (uint32_t)n_frames * p.chunks_per_frame;
+        HIP_TRY(ctx, launch_encode_framewise(p, fw_waves, fast_in, aligned_out, ctx->stream));
+    }
     else HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;

@@ -73,7 +73,7 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 // Slot layout with at least as many frames as resident workgroups: no inter-workgroup state at all.
-hipError_t launch_encode_framewise(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
+hipError_t launch_encode_framewise(const EncParams &p, int waves, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s);

@@ -319,23 +319,25 @@ struct ChunkRef {
     bool valid, hasA, hasB;
 };
 
-__device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, int tidw) {
+__device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, int tidw, uint32_t chunk_tiles = kEncChunkTiles) {
     ChunkRef k;
     k.c = c;
     k.valid = c < p.n_chunks;
     k.f = k.valid ? c / p.chunks_per_frame : 0u;
     k.cf = k.valid ? c - k.f * p.chunks_per_frame : 0u;
-    k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
+    k.t0 = k.cf * chunk_tiles + 2u * (uint32_t)tidw;
     k.hasA = k.valid && k.t0 < p.T;
     k.hasB = k.valid && k.t0 + 1u < p.T;
     return k;
 }
 
-template <bool FAST_IN>
+template <bool FAST_IN, bool ZERO = true>
 __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                            uint32_t (&vb)[16]) {
+    if (ZERO) {   // (callers that never read registers of tile-less lanes skip this)
 #pragma unroll
-    for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
+        for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
+    }
     const uint8_t *img = p.images + (size_t)k.f * p.frame_pixels;
     if (FAST_IN) {   // W % 16 == 0, base 16-aligned: both tiles in one strip, one 16-B load per row
         if (k.hasA) {
@@ -631,14 +633,63 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
 // waiting on any other workgroup (so nothing to prove about residency either).  Same per-chunk
 // pipeline as above: nxt's image loads in flight while cur is reduced, packed into the wave's
 // LDS region and stored; one workgroup barrier per chunk (the wave totals).
+template <int WAVES>
 struct EncSharedFW {
-    uint64_t pay[kEncWaves][kWaveWords + 64];   // + one trash word per lane (pack_two_tiles)
-    uint32_t tot[2][kEncWaves];
+    uint64_t pay[WAVES][kWaveWords + 64];   // + one trash word per lane (pack_two_tiles)
+    uint32_t tot[2][WAVES];
 };
 
-template <bool FAST_IN, bool ALIGNED_OUT>
-__global__ __launch_bounds__(kEncThreads) void encode_framewise_kernel(EncParams p) {
-    __shared__ __attribute__((aligned(16))) EncSharedFW sh;
+// One pipeline step of the frame-wise encoder: RC holds cur's pixels, RN receives nxt's.
+#define DBDE_FW_STEP(RCA, RCB, RNA, RNB)                                                                           \
+    {                                                                                                              \
+        const uint32_t par = it & 1u;                                                                              \
+        /* next chunk: same frame, or the first chunk of this workgroup's next frame */                            \
+        uint32_t nf = f, ncf = cf + 1u;                                                                            \
+        if (ncf == cpf) { ncf = 0; nf = f + gridDim.x; }                                                           \
+        const ChunkRef nxt = chunk_ref(p, nf < n_frames ? nf * cpf + ncf : 0xFFFFFFFFu, tid, WAVES * 128u);                      \
+        load_chunk<FAST_IN, false>(p, nxt, RNA, RNB);                                                              \
+        /* statistics (dbde_util.cpp:30-68) and offsets inside the wave */                                         \
+        uint32_t mnA, mxA, mnB, mxB;                                                                               \
+        tile_minmax(RCA, mnA, mxA);                                                                                \
+        tile_minmax(RCB, mnB, mxB);                                                                                \
+        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;                                             \
+        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;                                             \
+        const uint32_t incl = wave_scan_incl(dA + dB);                                                             \
+        const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);                                                 \
+        if (lane == 0) sh.tot[par][wave] = wtot;                                                                   \
+        __syncthreads();                                                                                           \
+        uint32_t wbase = 0, cur_total = 0;                                                                         \
+        _Pragma("unroll") for (int k = 0; k < WAVES; k++) {                                                        \
+            const uint32_t tk = sh.tot[par][k];                                                                    \
+            wbase += k < wave ? tk : 0u;                                                                           \
+            cur_total += tk;                                                                                       \
+        }                                                                                                          \
+        /* pack into the wave's LDS region, then LDS -> global (16 B per lane) */                                  \
+        if (wtot != 0u) {                                                                                          \
+            const uint32_t offA = incl - (dA + dB), offB = offA + dA;                                              \
+            const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB))); \
+            if (all8) {                                                                                            \
+                if (cur.hasA) pack_tile_d8(RCA, mnA, pay, offA);                                                   \
+                if (cur.hasB) pack_tile_d8(RCB, mnB, pay, offB);                                                   \
+            } else {                                                                                               \
+                pack_two_tiles(RCA, mnA, dA, offA, RCB, mnB, dB, offB, pay, kWaveWords + (uint32_t)lane);          \
+            }                                                                                                      \
+        }                                                                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                                     \
+        __builtin_amdgcn_wave_barrier();                                                                           \
+        store_wave_part<ALIGNED_OUT>(p, cur, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, inf, pay, lane); \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                                     \
+        __builtin_amdgcn_wave_barrier();                                                                           \
+        if (tid == 0 && (cf == 0u || cf == cpf - 1u)) scanner_frame_fields<ALIGNED_OUT>(p, f, cf, inf + cur_total, 0u); \
+        inf = ncf == 0u ? 0u : inf + cur_total;                                                                    \
+        f = nf; cf = ncf;                                                                                          \
+        cur = nxt;                                                                                                 \
+        it++;                                                                                                      \
+    }
+
+template <bool FAST_IN, bool ALIGNED_OUT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void encode_framewise_kernel(EncParams p) {
+    __shared__ __attribute__((aligned(16))) EncSharedFW<WAVES> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cpf = p.chunks_per_frame;
     const uint32_t n_frames = p.n_chunks / cpf;
@@ -646,68 +697,21 @@ __global__ __launch_bounds__(kEncThreads) void encode_framewise_kernel(EncParams
 
     uint32_t f = blockIdx.x, cf = 0;
     if (f >= n_frames) return;
-    ChunkRef cur = chunk_ref(p, f * cpf, tid);
+    ChunkRef cur = chunk_ref(p, f * cpf, tid, WAVES * 128u);
     uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-    load_chunk<FAST_IN>(p, cur, r0a, r0b);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { r0a[i] = 0; r0b[i] = 0; r1a[i] = 0; r1b[i] = 0; }   // lanes without tiles stay 0
+    load_chunk<FAST_IN, false>(p, cur, r0a, r0b);
     uint32_t inf = 0;   // payload words of this frame before cur
-
-    for (uint32_t it = 0; cur.valid; it++) {
-        const uint32_t par = it & 1u;
-        // next chunk: same frame, or the first chunk of this workgroup's next frame
-        uint32_t nf = f, ncf = cf + 1u;
-        if (ncf == cpf) { ncf = 0; nf = f + gridDim.x; }
-        const ChunkRef nxt = chunk_ref(p, nf < n_frames ? nf * cpf + ncf : 0xFFFFFFFFu, tid);
-        load_chunk<FAST_IN>(p, nxt, r1a, r1b);
-
-        // statistics (dbde_util.cpp:30-68) and offsets inside the wave
-        uint32_t mnA, mxA, mnB, mxB;
-        tile_minmax(r0a, mnA, mxA);
-        tile_minmax(r0b, mnB, mxB);
-        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
-        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
-        const uint32_t incl = wave_scan_incl(dA + dB);
-        const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
-        if (lane == 0) sh.tot[par][wave] = wtot;
-        __syncthreads();
-        uint32_t wbase = 0, cur_total = 0;
-#pragma unroll
-        for (int k = 0; k < kEncWaves; k++) {
-            const uint32_t tk = sh.tot[par][k];
-            wbase += k < wave ? tk : 0u;
-            cur_total += tk;
-        }
-
-        // pack into the wave's LDS region, then LDS -> global (16 B per lane)
-        if (wtot != 0u) {
-            const uint32_t offA = incl - (dA + dB), offB = offA + dA;
-            const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
-            if (all8) {
-                if (cur.hasA) pack_tile_d8(r0a, mnA, pay, offA);
-                if (cur.hasB) pack_tile_d8(r0b, mnB, pay, offB);
-            } else {
-#if DBDE_PACK2
-                pack_two_tiles(r0a, mnA, dA, offA, r0b, mnB, dB, offB, pay, kWaveWords + (uint32_t)lane);
-#else
-                pack_tile(r0a, mnA, dA, pay, offA);
-                pack_tile(r0b, mnB, dB, pay, offB);
-#endif
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        store_wave_part<ALIGNED_OUT>(p, cur, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, inf, pay, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (tid == 0 && (cf == 0u || cf == cpf - 1u))
-            scanner_frame_fields<ALIGNED_OUT>(p, f, cf, inf + cur_total, 0u);
-
-        inf = ncf == 0u ? 0u : inf + cur_total;
-        f = nf; cf = ncf;
-        cur = nxt;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { r0a[i] = r1a[i]; r0b[i] = r1b[i]; }
+    uint32_t it = 0;
+    // two steps per trip with the register sets swapped: no copy between them
+    while (cur.valid) {
+        DBDE_FW_STEP(r0a, r0b, r1a, r1b)
+        if (!cur.valid) break;
+        DBDE_FW_STEP(r1a, r1b, r0a, r0b)
     }
 }
+#undef DBDE_FW_STEP
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
     dim3 block(kEncThreads);
@@ -720,14 +724,21 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
     return hipGetLastError();
 }
 
-hipError_t launch_encode_framewise(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
+template <int WAVES>
+static hipError_t launch_fw(const EncParams &p, bool fast_in, bool aligned_out, uint32_t max_blocks, hipStream_t s) {
     const uint32_t n_frames = p.n_chunks / p.chunks_per_frame;
-    dim3 block(kEncThreads), grid(n_frames < p.grid_blocks ? n_frames : p.grid_blocks);
-    if (fast_in && aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<true, true>), grid, block, 0, s, p);
-    else if (fast_in) hipLaunchKernelGGL((encode_framewise_kernel<true, false>), grid, block, 0, s, p);
-    else if (aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<false, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((encode_framewise_kernel<false, false>), grid, block, 0, s, p);
+    dim3 block(64 * WAVES), grid(n_frames < max_blocks ? n_frames : max_blocks);
+    if (fast_in && aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<true, true, WAVES>), grid, block, 0, s, p);
+    else if (fast_in) hipLaunchKernelGGL((encode_framewise_kernel<true, false, WAVES>), grid, block, 0, s, p);
+    else if (aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<false, true, WAVES>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((encode_framewise_kernel<false, false, WAVES>), grid, block, 0, s, p);
     return hipGetLastError();
+}
+
+// p.chunks_per_frame / p.n_chunks must be in units of (waves * 128)-tile chunks.
+hipError_t launch_encode_framewise(const EncParams &p, int waves, bool fast_in, bool aligned_out, hipStream_t s) {
+    if (waves == 4) return launch_fw<4>(p, fast_in, aligned_out, p.grid_blocks * 2u, s);
+    return launch_fw<8>(p, fast_in, aligned_out, p.grid_blocks, s);
 }
 
 // Resident workgroups per CU of the encoder (occupancy query; LDS- and VGPR-bound).

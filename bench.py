@@ -153,7 +153,8 @@ def main():
     alg = raw + packed_bytes                      # encode reads raw, writes packed; decode the reverse
     enc_gbps = alg / (enc_ms * 1e-3) / 1e9
     dec_gbps = alg / (dec_ms * 1e-3) / 1e9
-    enc_name = "dbde::encode_framewise_kernel" if (slot and B >= 256) else "dbde::encode_kernel"
+    fw_min = int(os.environ.get("DBDE_HIP_FRAMEWISE_MIN", "0"))
+    enc_name = "dbde::encode_framewise_kernel" if (slot and fw_min and B >= fw_min) else "dbde::encode_kernel"
     dom = (enc_name, enc_ms, enc_gbps) if enc_ms >= dec_ms else ("dbde::decode_kernel", dec_ms, dec_gbps)
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[2], 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(dom[2] / HBM_PEAK_GBPS, 4), "traffic": None,

@@ -254,9 +254,9 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         ctx->lb_bytes = have;
     }
     const size_t zero_bytes = lb_need;
-    // Frame-wise kernel: slot layout and enough frames to give every resident workgroup its own
-    // ($DBDE_HIP_FRAMEWISE_MIN overrides the threshold; 0 disables).
-    uint32_t fw_min = ctx->enc_grid / 2;
+    // Frame-wise kernel (opt-in, $DBDE_HIP_FRAMEWISE_MIN = smallest batch that uses it): slot layout,
+    // a workgroup owns whole frames.  Measured slower than the scanning encoder (locality), kept for A/B.
+    uint32_t fw_min = 0;   // off by default: the scanning encoder is faster at every batch size
     if (const char *e = getenv("DBDE_HIP_FRAMEWISE_MIN")) fw_min = (uint32_t)strtoul(e, nullptr, 0);
     const bool framewise = slot_stride != 0 && fw_min != 0 && (uint32_t)n_frames >= fw_min;
     span_begin(ctx, 0);

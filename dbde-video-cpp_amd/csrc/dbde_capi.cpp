@@ -310,8 +310,11 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
         return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
-    if (g.cpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
-    const uint64_t n_chunks64 = (uint64_t)n_frames * g.cpf;
+    uint32_t dec_ct = 512;   // tiles per decode workgroup ($DBDE_HIP_DEC_CHUNK = 256 for smaller workgroups)
+    if (const char *e = getenv("DBDE_HIP_DEC_CHUNK")) dec_ct = atoi(e) == 256 ? 256u : 512u;
+    const uint32_t dcpf = (g.T + dec_ct - 1) / dec_ct;
+    if (dcpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
+    const uint64_t n_chunks64 = (uint64_t)n_frames * dcpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64 + (size_t)n_frames, sizeof(uint32_t));
@@ -327,7 +330,8 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     ip.frame_ok = ctx->frame_ok;
     ip.results = d_results;
     ip.T = g.T;
-    ip.chunks_per_frame = g.cpf;
+    ip.chunks_per_frame = dcpf;
+    ip.chunk_shift = dec_ct == 256u ? 8u : 9u;
     span_begin(ctx, 1);
     HIP_TRY(ctx, launch_decode_index(ip, n_frames, ctx->stream));
     span_end(ctx);
@@ -344,8 +348,9 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.w = g.w;
     p.h = g.h;
     p.T = g.T;
-    p.chunks_per_frame = g.cpf;
+    p.chunks_per_frame = dcpf;
     p.n_chunks = (uint32_t)n_chunks64;
+    p.chunk_tiles = dec_ct;
     const bool fast_img = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
     span_begin(ctx, 2);
     HIP_TRY(ctx, launch_decode(p, fast_img, ctx->stream));

@@ -51,6 +51,7 @@ struct DecParams {
     int W, H;
     uint32_t w, h, T;
     uint32_t chunks_per_frame, n_chunks;
+    uint32_t chunk_tiles;           // 512 or 256: tiles per workgroup
 };
 
 struct IdxParams {
@@ -61,6 +62,7 @@ struct IdxParams {
     uint32_t *frame_ok;             // out [n_frames]
     void *results;                  // optional dbde_hip_frame_result[n_frames]
     uint32_t T, chunks_per_frame;
+    uint32_t chunk_shift;           // log2(tiles per chunk)
 };
 
 struct FrameResultDev {             // layout of dbde_hip_frame_result

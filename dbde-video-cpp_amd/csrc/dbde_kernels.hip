@@ -72,6 +72,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 
 // Inclusive scan of one value per lane across the 256-thread block.
 // Returns this lane's inclusive prefix; block_total = sum over the block.
+template <int NW = 4>
 __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *s_wave_tot, int lane, int wave,
                                                     uint32_t &block_total) {
     uint32_t incl = v;
@@ -82,9 +83,14 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *s_wave
     }
     if (lane == 63) s_wave_tot[wave] = incl;
     __syncthreads();
-    uint32_t t0 = s_wave_tot[0], t1 = s_wave_tot[1], t2 = s_wave_tot[2], t3 = s_wave_tot[3];
-    uint32_t base = (wave > 0 ? t0 : 0u) + (wave > 1 ? t1 : 0u) + (wave > 2 ? t2 : 0u);
-    block_total = t0 + t1 + t2 + t3;
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const uint32_t tk = s_wave_tot[k];
+        base += k < wave ? tk : 0u;
+        tot += tk;
+    }
+    block_total = tot;
     return base + incl;
 }
 
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
             // position of this piece's byte 0 relative to the array start
             const long long pos0 = 16ll * i - (long long)head;
             uint32_t sum_lo = 0, sum_hi = 0;
-            const uint32_t k_lo = (uint32_t)((pos0 < 0 ? 0 : pos0) >> 9);
+            const uint32_t k_lo = (uint32_t)((pos0 < 0 ? 0 : pos0) >> p.chunk_shift);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 uint32_t x = wv[j];
@@ -801,8 +807,8 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
                 bad_depth |= (x & 0xF0F0F0F0u) | ((x + 0x77777777u) & 0x80808080u);   // any byte > 8
                 // a dword belongs to one chunk unless it straddles a 512-byte boundary of the array
                 const long long pc = pj < 0 ? 0 : pj;
-                const uint32_t kj = (uint32_t)(pc >> 9);
-                const uint32_t kend = (uint32_t)((pj + 3 < 0 ? 0 : pj + 3) >> 9);
+                const uint32_t kj = (uint32_t)(pc >> p.chunk_shift);
+                const uint32_t kend = (uint32_t)((pj + 3 < 0 ? 0 : pj + 3) >> p.chunk_shift);
                 if (kj == kend) {
                     const uint32_t sb = __builtin_amdgcn_sad_u8(x, 0u, 0u);
                     if (kj == k_lo) sum_lo += sb; else sum_hi += sb;
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
                     for (int b = 0; b < 4; b++) {
                         const long long pb = pj + b;
                         const uint32_t v = (x >> (8 * b)) & 0xFFu;
-                        if (pb >= 0) { if ((uint32_t)(pb >> 9) == k_lo) sum_lo += v; else sum_hi += v; }
+                        if (pb >= 0) { if ((uint32_t)(pb >> p.chunk_shift) == k_lo) sum_lo += v; else sum_hi += v; }
                     }
                 }
             }
@@ -933,15 +939,20 @@ __device__ __forceinline__ void store_tile_generic(uint8_t *img, int W, int H, u
     }
 }
 
-// LDS image of a chunk's payload: up to 15 bytes of alignment shift + 32 KiB + one qword of
-// over-read, rounded up to whole 256-byte swizzle groups.
-constexpr uint32_t kDecLdsSlots = ((15u + kMaxChunkWords * 8u + 8u + 15u) / 16u + 15u) / 16u * 16u;
-constexpr int kDecMaxPieces = (kDecLdsSlots + kBlockThreads - 1) / kBlockThreads;   // 16-B pieces per thread
+// LDS image of a chunk's payload: up to 15 bytes of alignment shift + 64 B per tile + one qword
+// of over-read, rounded up to whole 256-byte swizzle groups.
+template <int CT> struct DecGeom {
+    static constexpr int kThreads = CT / 2;
+    static constexpr int kWaves = CT / 128;
+    static constexpr uint32_t kSlots = ((15u + CT * 64u + 8u + 15u) / 16u + 15u) / 16u * 16u;
+    static constexpr int kPieces = (kSlots + kThreads - 1) / kThreads;   // 16-B pieces per thread
+};
 
-template <bool FAST_IMG>
-__global__ __launch_bounds__(kBlockThreads) void decode_kernel(DecParams p) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_in[kDecLdsSlots * 2];
-    __shared__ uint32_t s_wave_tot[4];
+template <bool FAST_IMG, int CT>
+__global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
+    typedef DecGeom<CT> G;
+    __shared__ __attribute__((aligned(16))) uint64_t s_in[G::kSlots * 2];
+    __shared__ uint32_t s_wave_tot[G::kWaves];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c = blockIdx.x;
@@ -955,7 +966,7 @@ __global__ __launch_bounds__(kBlockThreads) void decode_kernel(DecParams p) {
     if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
 
     const uint8_t *fb = p.stream + foff;
-    const uint32_t t0 = cf * kChunkTiles + 2u * (uint32_t)tid;
+    const uint32_t t0 = cf * (uint32_t)CT + 2u * (uint32_t)tid;
     const bool hasA = t0 < p.T, hasB = t0 + 1u < p.T;
     const uint8_t *depth_arr = fb + 24;
     const uint8_t *min_arr = fb + 28 + p.T;
@@ -972,22 +983,29 @@ __global__ __launch_bounds__(kBlockThreads) void decode_kernel(DecParams p) {
     // inside one 256-byte group so the source side remains coalesced.  No staging registers.
     const uint32_t n16r = (n16 + 15u) & ~15u;
 #pragma unroll
-    for (int j = 0; j < kDecMaxPieces; j++) {
-        const uint32_t i = (uint32_t)tid + (uint32_t)j * kBlockThreads;
+    for (int j = 0; j < G::kPieces; j++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)j * G::kThreads;
         const uint32_t src_slot = swz16(i);
         if (i < n16r && src_slot < n16) {
-            const uint32_t wave_slot0 = (uint32_t)j * kBlockThreads + (uint32_t)wave * 64u;
+            const uint32_t wave_slot0 = (uint32_t)j * G::kThreads + (uint32_t)wave * 64u;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(asrc + 16ull * src_slot),
                 (__attribute__((address_space(3))) void *)(&s_in[2u * wave_slot0]), 16, 0, DBDE_NT ? 2 : 0);
         }
     }
     uint32_t dA = 0, dB = 0, mA = 0, mB = 0;
-    if (hasA) { dA = depth_arr[t0]; mA = min_arr[t0]; }
-    if (hasB) { dB = depth_arr[t0 + 1]; mB = min_arr[t0 + 1]; }
+    // t0 is even: when both byte arrays start at even addresses the lane's two tiles are one u16 each
+    if (hasB && ((reinterpret_cast<uintptr_t>(depth_arr) | reinterpret_cast<uintptr_t>(min_arr)) & 1u) == 0u) {
+        const uint32_t d2 = *reinterpret_cast<const uint16_t *>(depth_arr + t0);
+        const uint32_t m2 = *reinterpret_cast<const uint16_t *>(min_arr + t0);
+        dA = d2 & 0xFFu; dB = d2 >> 8; mA = m2 & 0xFFu; mB = m2 >> 8;
+    } else {
+        if (hasA) { dA = depth_arr[t0]; mA = min_arr[t0]; }
+        if (hasB) { dB = depth_arr[t0 + 1]; mB = min_arr[t0 + 1]; }
+    }
 
     uint32_t chunk_total;   // equals chunk_words for a validated frame
-    const uint32_t incl = block_scan_incl(dA + dB, s_wave_tot, lane, wave, chunk_total);   // barrier inside
+    const uint32_t incl = block_scan_incl<G::kWaves>(dA + dB, s_wave_tot, lane, wave, chunk_total);   // barrier inside
     const uint32_t offA = incl - (dA + dB), offB = offA + dA;
 
     uint32_t va[16], vb[16];
@@ -1022,9 +1040,14 @@ __global__ __launch_bounds__(kBlockThreads) void decode_kernel(DecParams p) {
 }
 
 hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s) {
-    dim3 grid(p.n_chunks), block(kBlockThreads);
-    if (fast_img) hipLaunchKernelGGL((decode_kernel<true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((decode_kernel<false>), grid, block, 0, s, p);
+    dim3 grid(p.n_chunks);
+    if (p.chunk_tiles == 256u) {
+        if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 256>), grid, dim3(128), 0, s, p);
+        else hipLaunchKernelGGL((decode_kernel<false, 256>), grid, dim3(128), 0, s, p);
+    } else {
+        if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 512>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((decode_kernel<false, 512>), grid, dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 

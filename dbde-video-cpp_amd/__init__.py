@@ -41,6 +41,9 @@ C_ABI_SYMBOLS = [
     "dbde_hip_pack_frame_header", "dbde_hip_pack_video_header",
     "dbde_hip_unpack_frame_header", "dbde_hip_unpack_video_header",
     "dbde_hip_timing_enable", "dbde_hip_timing_read",
+    "dbde_hip_stream_handle", "dbde_hip_device_index",
+    "dbde_hip_writer_open", "dbde_hip_writer_put", "dbde_hip_writer_error", "dbde_hip_writer_close",
+    "dbde_hip_reader_open", "dbde_hip_reader_next", "dbde_hip_reader_close",
 ]
 
 
@@ -129,6 +132,24 @@ def lib():
     L.dbde_hip_timing_enable.argtypes = [vp, i]
     L.dbde_hip_timing_read.restype = i
     L.dbde_hip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i]
+    L.dbde_hip_stream_handle.restype = vp
+    L.dbde_hip_stream_handle.argtypes = [vp]
+    L.dbde_hip_device_index.restype = i
+    L.dbde_hip_device_index.argtypes = [vp]
+    L.dbde_hip_writer_open.restype = i
+    L.dbde_hip_writer_open.argtypes = [vp, C.c_char_p, i, i, C.c_double, i, C.POINTER(vp)]
+    L.dbde_hip_writer_put.restype = i
+    L.dbde_hip_writer_put.argtypes = [vp, vp, i, u64, vp, vp]
+    L.dbde_hip_writer_error.restype = C.c_char_p
+    L.dbde_hip_writer_error.argtypes = [vp]
+    L.dbde_hip_writer_close.restype = i
+    L.dbde_hip_writer_close.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.dbde_hip_reader_open.restype = i
+    L.dbde_hip_reader_open.argtypes = [vp, C.c_char_p, i, C.POINTER(VideoHeader), C.POINTER(vp)]
+    L.dbde_hip_reader_next.restype = i
+    L.dbde_hip_reader_next.argtypes = [vp, vp, i, C.POINTER(FrameHeader), C.POINTER(i)]
+    L.dbde_hip_reader_close.restype = None
+    L.dbde_hip_reader_close.argtypes = [vp]
     _lib = L
     return L
 
@@ -322,6 +343,13 @@ class Codec:
                                            canvas.ctypes.data + off)
         return canvas
 
+    # ---- .dbde files: batched writer / reader (include/dbde_hip.h, file I/O) ----------------
+    def open_writer(self, path, W, H, frame_hz=30.0, batch_frames=16):
+        return FileWriter(self, path, W, H, frame_hz, batch_frames)
+
+    def open_reader(self, path, batch_frames=16):
+        return FileReader(self, path, batch_frames)
+
     # ---- timing hook ------------------------------------------------------------------
     def timing(self, on=True):
         self._check(self.L.dbde_hip_timing_enable(self.h, 1 if on else 0), "dbde_hip_timing_enable")
@@ -331,3 +359,82 @@ class Codec:
         n = (C.c_uint64 * 3)()
         self._check(self.L.dbde_hip_timing_read(self.h, ms, n, 1 if reset else 0), "dbde_hip_timing_read")
         return {"encode": (ms[0], n[0]), "decode_index": (ms[1], n[1]), "decode": (ms[2], n[2])}
+
+
+class FileWriter:
+    """dbde_hip_writer_*: appends device-resident frames to a .dbde file, a batch per launch."""
+
+    def __init__(self, codec, path, W, H, frame_hz, batch_frames):
+        self.codec, self.W, self.H = codec, W, H
+        self.h = C.c_void_p()
+        rc = codec.L.dbde_hip_writer_open(codec.h, os.fsencode(path), W, H, frame_hz, batch_frames, C.byref(self.h))
+        if rc != OK:
+            raise DbdeError(f"dbde_hip_writer_open({path!r}) failed ({rc})")
+
+    def put(self, images, n, first_index=0, indices=None, elapsed_ns=None):
+        rc = self.codec.L.dbde_hip_writer_put(self.h, images.data_ptr(), n, first_index,
+                                              indices.data_ptr() if indices is not None else None,
+                                              elapsed_ns.data_ptr() if elapsed_ns is not None else None)
+        if rc != OK:
+            raise DbdeError(f"dbde_hip_writer_put failed ({rc}): {self.codec.L.dbde_hip_writer_error(self.h).decode()}")
+
+    def close(self):
+        """Returns (frames written, file bytes)."""
+        if not self.h.value:
+            return None
+        fr, by = C.c_uint64(0), C.c_uint64(0)
+        rc = self.codec.L.dbde_hip_writer_close(self.h, C.byref(fr), C.byref(by))
+        self.h = C.c_void_p()
+        if rc != OK:
+            raise DbdeError(f"dbde_hip_writer_close failed ({rc})")
+        return fr.value, by.value
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class FileReader:
+    """dbde_hip_reader_*: walks a .dbde file a batch at a time, images land in HBM."""
+
+    def __init__(self, codec, path, batch_frames):
+        self.codec, self.batch = codec, batch_frames
+        self.h = C.c_void_p()
+        vh = VideoHeader()
+        rc = codec.L.dbde_hip_reader_open(codec.h, os.fsencode(path), batch_frames, C.byref(vh), C.byref(self.h))
+        if rc != OK:
+            raise DbdeError(f"dbde_hip_reader_open({path!r}) failed ({rc})")
+        self.video_header = (vh.u64s, vh.height, vh.width, vh.frame_hz)
+        self.W, self.H = int(vh.width), int(vh.height)
+
+    def next(self, max_frames=None, images=None):
+        """-> (images[:n] device tensor, [(u64s, index, elapsed_ns)] * n); n == 0 ends the walk."""
+        m = self.batch if max_frames is None else min(max_frames, self.batch)
+        if images is None:
+            images = torch.empty((m, self.H, self.W), dtype=torch.uint8, device=self.codec.device)
+        hdr = (FrameHeader * max(m, 1))()
+        n = C.c_int(0)
+        rc = self.codec.L.dbde_hip_reader_next(self.h, images.data_ptr(), m, hdr, C.byref(n))
+        if rc != OK:
+            raise DbdeError(f"dbde_hip_reader_next failed ({rc}): {self.codec.L.dbde_hip_last_error(self.codec.h).decode()}")
+        return images[:n.value], [(hdr[k].u64s, hdr[k].index, hdr[k].elapsed_ns) for k in range(n.value)]
+
+    def __iter__(self):
+        while True:
+            imgs, hdrs = self.next()
+            if not hdrs:
+                return
+            yield imgs, hdrs
+
+    def close(self):
+        if self.h.value:
+            self.codec.L.dbde_hip_reader_close(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

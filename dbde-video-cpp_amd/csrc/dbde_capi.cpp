@@ -200,6 +200,8 @@ int dbde_hip_sync(dbde_hip_ctx *ctx) {
 
 const char *dbde_hip_last_error(const dbde_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 const char *dbde_hip_device_arch(const dbde_hip_ctx *ctx) { return ctx ? ctx->arch.c_str() : ""; }
+void *dbde_hip_stream_handle(const dbde_hip_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+int dbde_hip_device_index(const dbde_hip_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 // ---- sizes -----------------------------------------------------------------------------------
 

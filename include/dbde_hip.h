@@ -73,6 +73,9 @@ int dbde_hip_sync(dbde_hip_ctx *ctx);
 const char *dbde_hip_last_error(const dbde_hip_ctx *ctx);
 /* Name of the device the context runs on (e.g. "gfx950:sramecc+:xnack-"). */
 const char *dbde_hip_device_arch(const dbde_hip_ctx *ctx);
+/* The hipStream_t and HIP device index the context was created with. */
+void *dbde_hip_stream_handle(const dbde_hip_ctx *ctx);
+int dbde_hip_device_index(const dbde_hip_ctx *ctx);
 
 /* ---- sizes ---------------------------------------------------------------------------- */
 
@@ -163,6 +166,42 @@ size_t dbde_hip_pack_video_header(const dbde_hip_video_header *vh, uint8_t *targ
 dbde_hip_frame_header dbde_hip_unpack_frame_header(uint8_t **packed);
 /* dbde_unpack_video_header (dbde_util.cpp:347-359): advances *packed by 28. */
 dbde_hip_video_header dbde_hip_unpack_video_header(uint8_t **packed);
+
+/* ---- file I/O: batched .dbde writer and reader -------------------------------------------- */
+/* The other end of the path: the reference reads a file frame by frame
+ * (dbde_start_file_walk / dbde_walk_a_file / dbde_end_file_walk, dbde_util.cpp:362-426; that
+ * API itself is served by libdbde_util_hip.so) and has no writer, its test hand-rolls one
+ * (dbde_util_test.cpp:204-211).  These move whole batches: images are DEVICE buffers, the
+ * compressed bytes cross PCIe through two pinned windows so that file I/O of one batch
+ * overlaps the kernels of the next.  Files are byte-identical to a video header followed by
+ * dbde_pack_frame output for every frame. */
+typedef struct dbde_hip_writer dbde_hip_writer;
+typedef struct dbde_hip_reader dbde_hip_reader;
+
+/* Creates `path` and writes the 28-byte video header {3, H, W, frame_hz}
+ * (dbde_pack_video_header).  batch_frames = frames encoded per launch (window size). */
+int dbde_hip_writer_open(dbde_hip_ctx *ctx, const char *path, int W, int H, double frame_hz,
+                         int batch_frames, dbde_hip_writer **out);
+/* Appends n_frames device-resident images (arguments as dbde_hip_encode_frames).  On return
+ * d_images may be reused; the bytes reach the file by the next put or by close. */
+int dbde_hip_writer_put(dbde_hip_writer *w, const uint8_t *d_images, int n_frames,
+                        uint64_t first_index, const uint64_t *d_indices,
+                        const uint64_t *d_elapsed_ns);
+const char *dbde_hip_writer_error(const dbde_hip_writer *w);
+/* Flushes, closes the file and frees the writer; totals are optional outputs. */
+int dbde_hip_writer_close(dbde_hip_writer *w, uint64_t *frames_written, uint64_t *bytes_written);
+
+/* Opens `path`, parses and checks the video header with the walker's limits
+ * (dbde_util.cpp:371-381: u64s == 3, 0 < H, W, H*W <= 0x37FFFFFF) and starts reading. */
+int dbde_hip_reader_open(dbde_hip_ctx *ctx, const char *path, int batch_frames,
+                         dbde_hip_video_header *vh, dbde_hip_reader **out);
+/* Decodes the next up-to-max_frames frames (capped at batch_frames) into d_images (device,
+ * W*H bytes each) and their headers into `headers` (host, optional).  *n_out = frames
+ * delivered; 0 = end of file or, as dbde_walk_a_file returns false (dbde_util.cpp:412-420),
+ * the first frame that is truncated or does not parse -- the walk ends there. */
+int dbde_hip_reader_next(dbde_hip_reader *r, uint8_t *d_images, int max_frames,
+                         dbde_hip_frame_header *headers, int *n_out);
+void dbde_hip_reader_close(dbde_hip_reader *r);
 
 /* ---- kernel timing hook for bench.py ---------------------------------------------------- */
 /* When enabled, every encode / decode call brackets its kernels with HIP events on the

@@ -22,10 +22,20 @@ def shard_frames(n_frames, rank, world):
     return lo, hi
 
 
-def gather_stream(segment, nbytes, dst=0, group=None, out=None):
+MAX_MESSAGE_BYTES = 1 << 30   # a rank's segment travels in pieces of at most this many bytes
+
+
+def _pieces(nbytes, piece):
+    return [(at, min(piece, nbytes - at)) for at in range(0, nbytes, piece)]
+
+
+def gather_stream(segment, nbytes, dst=0, group=None, out=None, max_message_bytes=None):
     """Gathers every rank's first `nbytes` bytes of `segment` (uint8, 1-D) to rank `dst`, in rank
     order.  Returns (stream, sizes) on dst -- `stream` holds sum(sizes) bytes -- and (None, sizes)
-    elsewhere.  `out` may supply the destination buffer on dst (>= sum(sizes) bytes)."""
+    elsewhere.  `out` may supply the destination buffer on dst (>= sum(sizes) bytes).  Segments
+    of many GB (1024 frames of 4096x3072 are 13 GB) are split into <= max_message_bytes pieces,
+    all posted in one group; both ends derive the same piece boundaries from the gathered sizes."""
+    piece = int(max_message_bytes or MAX_MESSAGE_BYTES)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = segment.device
@@ -42,15 +52,16 @@ def gather_stream(segment, nbytes, dst=0, group=None, out=None):
         for r in range(world):
             if r == rank:
                 out[at:at + sizes[r]].copy_(segment[:sizes[r]])
-            elif sizes[r]:
-                ops.append(dist.P2POp(dist.irecv, out[at:at + sizes[r]], r, group))
+            else:
+                for o, n in _pieces(sizes[r], piece):
+                    ops.append(dist.P2POp(dist.irecv, out[at + o:at + o + n], r, group))
             at += sizes[r]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return out[:total], sizes
-    if sizes[rank]:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, segment[:sizes[rank]], dst, group)]):
-            w.wait()
+    ops = [dist.P2POp(dist.isend, segment[o:o + n], dst, group) for o, n in _pieces(sizes[rank], piece)]
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
     return None, sizes
 
 

@@ -40,8 +40,11 @@ def _worker(rank, world, port, q):
     seg = torch.from_numpy(np.concatenate(frames + [np.zeros(16, np.uint8)]))
     nbytes = sum(len(f) for f in frames)
     stream, sizes = dd.gather_stream(seg, nbytes, dst=0)
+    # the same gather with each segment split into many small messages
+    stream2, sizes2 = dd.gather_stream(seg, nbytes, dst=0, max_message_bytes=97)
+    assert sizes2 == sizes
     if rank == 0:
-        assert sum(sizes) == stream.numel()
+        assert sum(sizes) == stream.numel() and torch.equal(stream, stream2)
         # the gathered stream is exactly what one rank would have produced for all N frames
         want = np.concatenate([ora.pack_frame(f, ora.synth_frame(1, SEED, f, W, H), W, H) for f in range(N)])
         ok = stream.numpy().tobytes() == want.tobytes()

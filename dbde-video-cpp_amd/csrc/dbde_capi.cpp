@@ -313,7 +313,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
         return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
     uint32_t dec_ct = 512;   // tiles per decode workgroup ($DBDE_HIP_DEC_CHUNK = 256 for smaller workgroups)
-    if (const char *e = getenv("DBDE_HIP_DEC_CHUNK")) dec_ct = atoi(e) == 256 ? 256u : 512u;
+    if (const char *e = getenv("DBDE_HIP_DEC_CHUNK")) dec_ct = atoi(e) == 256 ? 256u : (atoi(e) == 1024 ? 1024u : 512u);
     const uint32_t dcpf = (g.T + dec_ct - 1) / dec_ct;
     if (dcpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
     const uint64_t n_chunks64 = (uint64_t)n_frames * dcpf;
@@ -333,7 +333,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     ip.results = d_results;
     ip.T = g.T;
     ip.chunks_per_frame = dcpf;
-    ip.chunk_shift = dec_ct == 256u ? 8u : 9u;
+    ip.chunk_shift = dec_ct == 256u ? 8u : (dec_ct == 1024u ? 10u : 9u);
     span_begin(ctx, 1);
     HIP_TRY(ctx, launch_decode_index(ip, n_frames, ctx->stream));
     span_end(ctx);

@@ -896,23 +896,54 @@ hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s) 
     return hipGetLastError();
 }
 
-// Row r of a tile is the 8*d-bit integer at byte (r*d) of the tile payload: fetch the two
-// qwords that hold it from the swizzled LDS image, funnel-shift, expand, add the minimum.
-__device__ __forceinline__ void unpack_tile_from_lds(const uint64_t *s_in, uint32_t byte_base, uint32_t d,
+// Physical byte address of logical byte address A in the 16-byte-slot swizzled LDS image
+// (slot ^= (slot >> 4) & 15, i.e. the permutation stays inside a 256-byte group).
+__device__ __forceinline__ uint32_t swz_byte16(uint32_t A) { return A ^ ((A >> 4) & 0xF0u); }
+
+// Row r of a tile is the 8*d-bit integer at byte (r*d) of the tile payload.  Rows start on
+// byte boundaries, so the 8 bytes that hold a row come out of the two enclosing qwords with
+// byte alignment ops (v_alignbyte) instead of 64-bit shifts; the two 4d-bit halves are split
+// with v_alignbit and expanded with v_bfe.  The minimum is added byte-wise with wrap-around, as
+// the reference's _mm_add_epi8 does (dbde_util.cpp:245-277).
+__device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_img, uint32_t byte_base, uint32_t d,
                                                      uint32_t mn, uint32_t (&v)[16]) {
-    const uint32_t m4 = mn * 0x01010101u;
-    const uint64_t keep = d >= 8u ? ~0ull : ((1ull << (8u * d)) - 1ull);
+    const uint32_t mn4 = mn * 0x01010101u;
+    const uint32_t m1 = ((1u << d) - 1u) * 0x00010001u;            // d-bit fields in 16-bit lanes
+    const uint32_t m2 = (1u << (2u * d)) - 1u;                     // 2d <= 16
+    const uint32_t m4 = d >= 8u ? 0xFFFFFFFFu : ((1u << (4u * d)) - 1u);
+    const bool d8 = d >= 8u;
+    uint32_t a = byte_base;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const uint32_t a = byte_base + d * (uint32_t)r;
-        const uint32_t q = a >> 3;
-        const uint32_t sh = (a & 7u) * 8u;
-        const uint64_t lo = s_in[swzq16(q)], hi = s_in[swzq16(q + 1u)];
-        const uint64_t row = (sh ? ((lo >> sh) | (hi << (64u - sh))) : lo) & keep;
-        uint32_t x, y;
-        expand_row(row, d, x, y);
-        v[2 * r] = add_bytes(x, m4);
-        v[2 * r + 1] = add_bytes(y, m4);
+        const uint32_t A0 = a & ~7u;
+        const uint2 lo = *reinterpret_cast<const uint2 *>(s_img + swz_byte16(A0));
+        const uint2 hi = *reinterpret_cast<const uint2 *>(s_img + swz_byte16(A0 + 8u));
+        const bool up = (a & 4u) != 0u;
+        const uint32_t t0 = up ? lo.y : lo.x, t1 = up ? hi.x : lo.y, t2 = up ? hi.y : hi.x;
+        const uint32_t r_lo = __builtin_amdgcn_alignbyte(t1, t0, a);   // bytes [a, a+4)
+        const uint32_t r_hi = __builtin_amdgcn_alignbyte(t2, t1, a);   // bytes [a+4, a+8)
+        const uint32_t g_lo = r_lo & m4;
+        const uint32_t g_hi = (d8 ? r_hi : __builtin_amdgcn_alignbit(r_hi, r_lo, 4u * d)) & m4;
+        // 4d-bit field -> two 2d-bit fields in 16-bit lanes -> four d-bit fields in bytes
+        const uint32_t f_lo = (g_lo & m2) | (__builtin_amdgcn_ubfe(g_lo, 2u * d, 2u * d) << 16);
+        const uint32_t f_hi = (g_hi & m2) | (__builtin_amdgcn_ubfe(g_hi, 2u * d, 2u * d) << 16);
+        const uint32_t x = (f_lo & m1) | (((f_lo >> d) & m1) << 8);
+        const uint32_t y = (f_hi & m1) | (((f_hi >> d) & m1) << 8);
+        v[2 * r] = add_bytes(x, mn4);
+        v[2 * r + 1] = add_bytes(y, mn4);
+        a += d;
+    }
+}
+
+// Depth-8 tile whose payload starts 8-byte aligned in the image: a row is one qword.
+__device__ __forceinline__ void unpack_tile_d8_from_lds(const uint8_t *s_img, uint32_t byte_base, uint32_t mn,
+                                                        uint32_t (&v)[16]) {
+    const uint32_t mn4 = mn * 0x01010101u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(s_img + swz_byte16(byte_base + 8u * (uint32_t)r));
+        v[2 * r] = add_bytes(q.x, mn4);
+        v[2 * r + 1] = add_bytes(q.y, mn4);
     }
 }
 
@@ -1009,8 +1040,17 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
     const uint32_t offA = incl - (dA + dB), offB = offA + dA;
 
     uint32_t va[16], vb[16];
-    unpack_tile_from_lds(s_in, shift + 8u * offA, dA, mA, va);
-    unpack_tile_from_lds(s_in, shift + 8u * offB, dB, mB, vb);
+    const uint8_t *s_img = reinterpret_cast<const uint8_t *>(s_in);
+    const uint32_t bA = shift + 8u * offA, bB = shift + 8u * offB;
+    // wave-uniform specialisation: every tile of the wave has depth 8 (rows are whole qwords)
+    const bool all8 = (shift & 7u) == 0u && __all((int)(dA == 8u && dB == 8u));
+    if (all8) {
+        unpack_tile_d8_from_lds(s_img, bA, mA, va);
+        unpack_tile_d8_from_lds(s_img, bB, mB, vb);
+    } else {
+        unpack_tile_from_lds(s_img, bA, dA, mA, va);
+        unpack_tile_from_lds(s_img, bB, dB, mB, vb);
+    }
 
     uint8_t *img = p.images + (size_t)f * p.frame_pixels;
     if (FAST_IMG) {
@@ -1044,6 +1084,9 @@ hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s) {
     if (p.chunk_tiles == 256u) {
         if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 256>), grid, dim3(128), 0, s, p);
         else hipLaunchKernelGGL((decode_kernel<false, 256>), grid, dim3(128), 0, s, p);
+    } else if (p.chunk_tiles == 1024u) {
+        if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 1024>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((decode_kernel<false, 1024>), grid, dim3(512), 0, s, p);
     } else {
         if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 512>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((decode_kernel<false, 512>), grid, dim3(256), 0, s, p);

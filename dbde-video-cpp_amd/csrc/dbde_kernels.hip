@@ -970,6 +970,21 @@ __device__ __forceinline__ void store_tile_generic(uint8_t *img, int W, int H, u
     }
 }
 
+// Workgroup -> chunk.  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD
+// b % 8), and each XCD has its own L2: with the identity mapping every XCD touches every
+// eighth 32 KB piece of the stream and of the image.  Here the launch is cut into groups of
+// 8 * kXcdRun chunks and, inside a group, XCD x takes kXcdRun CONSECUTIVE chunks (0.5 MB of
+// image, as much stream): measured 5-6 % faster on the full-size decode, flat for runs of
+// 8..256 chunks, slower below 8.  All XCDs still move through the buffers together.  A
+// trailing partial group keeps the identity mapping.
+constexpr uint32_t kXcdRun = 16;
+__device__ __forceinline__ uint32_t xcd_local_chunk(uint32_t b, uint32_t n_chunks) {
+    constexpr uint32_t kGroup = 8u * kXcdRun;
+    const uint32_t grp = b / kGroup, rem = b % kGroup;
+    if ((grp + 1u) * kGroup > n_chunks) return b;
+    return grp * kGroup + (rem & 7u) * kXcdRun + (rem >> 3);
+}
+
 // LDS image of a chunk's payload: up to 15 bytes of alignment shift + 64 B per tile + one qword
 // of over-read, rounded up to whole 256-byte swizzle groups.
 template <int CT> struct DecGeom {
@@ -986,7 +1001,7 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
     __shared__ uint32_t s_wave_tot[G::kWaves];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = xcd_local_chunk(blockIdx.x, p.n_chunks);
     const uint32_t f = c / p.chunks_per_frame;
     const uint32_t cf = c - f * p.chunks_per_frame;
     // everything the address arithmetic needs, requested together

@@ -541,9 +541,13 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
     uint64_t *pay = sh.pay[wave];
     uint32_t prev_meta = 0, prev_wbase = 0, prev_wtot = 0, prev_total = 0;
 
-    for (uint32_t it = 0;; it++) {
-        if (!cur.valid && !prev.valid) break;
-        const uint32_t par = it & 1u;
+    // One pipeline step.  `ca/cb` hold the pixels of cur (loaded one step ago), `na/nb` receive
+    // those of nxt; the caller alternates the two register sets instead of copying them, so the
+    // loads issued here are not waited for until the NEXT step's statistics.
+    // Returns 0 = finished, 1 = continue, 2 = failed (look-back time-out).
+    auto step = [&](const uint32_t par, uint32_t (&ca)[16], uint32_t (&cb)[16], uint32_t (&na)[16],
+                    uint32_t (&nb)[16]) __attribute__((always_inline)) -> int {
+        if (!cur.valid && !prev.valid) return 0;
 
         // ---- 1. mailbox of prev and the next ticket, before this iteration's loads --------------
         if (tid == 0) {
@@ -563,12 +567,12 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
             sh.lb[par][3] = tnew;
         }
         // ---- 2. image loads of nxt (consumed when the pipeline rotates) --------------------------
-        load_chunk<FAST_IN>(p, nxt, r1a, r1b);
+        load_chunk<FAST_IN>(p, nxt, na, nb);
 
         // ---- 3. statistics of cur (dbde_util.cpp:30-68), offsets inside the wave, AGG -------------
         uint32_t mnA, mxA, mnB, mxB;
-        tile_minmax(r0a, mnA, mxA);
-        tile_minmax(r0b, mnB, mxB);
+        tile_minmax(ca, mnA, mxA);
+        tile_minmax(cb, mnB, mxB);
         const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
         const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
         const uint32_t incl = wave_scan_incl(dA + dB);
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
         __syncthreads();   // ---- 4. the one workgroup barrier ----
         const uint32_t inf = sh.lb[par][0], glob = sh.lb[par][1], lb_ok = sh.lb[par][2];
         const uint32_t next_id = __builtin_amdgcn_readfirstlane(sh.lb[par][3]);
-        if (!lb_ok) return;
+        if (!lb_ok) return 2;
         uint32_t wbase = 0, cur_total = 0;
 #pragma unroll
         for (int k = 0; k < kEncWaves; k++) {
@@ -606,11 +610,11 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
             const uint32_t offA = incl - (dA + dB), offB = offA + dA;
             const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
             if (all8) {
-                if (cur.hasA) pack_tile_d8(r0a, mnA, pay, offA);
-                if (cur.hasB) pack_tile_d8(r0b, mnB, pay, offB);
+                if (cur.hasA) pack_tile_d8(ca, mnA, pay, offA);
+                if (cur.hasB) pack_tile_d8(cb, mnB, pay, offB);
             } else {
-                pack_tile(r0a, mnA, dA, pay, offA);
-                pack_tile(r0b, mnB, dB, pay, offB);
+                pack_tile(ca, mnA, dA, pay, offA);
+                pack_tile(cb, mnB, dB, pay, offB);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -623,9 +627,14 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
         prev_wtot = wtot;
         prev_total = cur_total;
         cur = nxt;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { r0a[i] = r1a[i]; r0b[i] = r1b[i]; }
         nxt = chunk_ref(p, next_id, tid);
+        return 1;
+    };
+    for (;;) {
+        int rc = step(0u, r0a, r0b, r1a, r1b);
+        if (rc != 1) break;
+        rc = step(1u, r1a, r1b, r0a, r0b);
+        if (rc != 1) break;
     }
 }
 

@@ -302,3 +302,99 @@ def test_framewise_many_frames(codec, oracle):
         assert torch.equal(back, imgs)
         assert all(r == (2, 7 + f, 0, int(s[f])) for f, r in enumerate(codec.parse_results(res)))
         del imgs, buf, back
+
+
+@pytest.mark.parametrize("W,H,n", [(1, 2000, 2), (3000, 1, 3), (16384, 8, 2), (12000, 17, 2), (8, 8, 1), (9, 9, 65),
+                                   (4096, 3072, 1)])
+def test_extreme_shapes(codec, oracle, W, H, n):
+    """Column / row images, one-tile frames, more frames than workgroups' worth of tiny chunks."""
+    import torch
+    imgs = codec.synth_frames("mixed", SEED, 7, n, W, H)
+    imgs_h = imgs.cpu().numpy()
+    for slot in (0, ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256):
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=7, slot_stride=slot)
+        for f in (0, n // 2, n - 1):
+            assert frames[f].tobytes() == oracle.pack_frame(7 + f, imgs_h[f], W, H).tobytes(), (W, H, slot, f)
+        total = int((offs[-1] + sizes[-1]).item())
+        back, res = codec.decode_frames(buf, lead, total, offs, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs), (W, H, slot)
+
+
+def test_ticket_mode_fallback(codec, oracle, dv):
+    """The encoder's fallback chunk assignment (tickets instead of static strides), forced."""
+    import os
+    import torch
+    W, H, n = 1024, 512, 24
+    os.environ["DBDE_HIP_EXPERIMENT"] = "1"
+    try:
+        c2 = dv.Codec(0)
+    finally:
+        os.environ.pop("DBDE_HIP_EXPERIMENT", None)
+    try:
+        imgs = c2.synth_frames("mixed", SEED, 0, n, W, H)
+        frames, (buf, lead, offs, sizes) = gpu_encode(c2, imgs, W, H, n)
+        imgs_h = imgs.cpu().numpy()
+        for f in range(n):
+            assert frames[f].tobytes() == oracle.pack_frame(f, imgs_h[f], W, H).tobytes()
+    finally:
+        c2.close()
+
+
+def test_argument_and_capacity_errors(codec, dv):
+    """C-ABI error behaviour: bad geometry, short buffers and null pointers are refused before
+    any launch; an empty batch is a no-op."""
+    import torch
+    W, H, n = 64, 64, 4
+    imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+    buf, lead, cap = codec.alloc_stream(W, H, n)
+    L, h = codec.L, codec.h
+    offs = torch.zeros(n, dtype=torch.int64, device=imgs.device)
+    # empty batch: OK, nothing written
+    buf.fill_(0xEE)
+    assert L.dbde_hip_encode_frames(h, imgs.data_ptr(), W, H, 0, 0, None, None, buf.data_ptr() + lead, cap, 0, None, None) == dv.OK
+    assert L.dbde_hip_decode_frames(h, buf.data_ptr() + lead, cap, offs.data_ptr(), W, H, 0, imgs.data_ptr(), None) == dv.OK
+    codec.sync()
+    assert bool((buf == 0xEE).all())
+    # geometry
+    for (w_, h_) in ((0, 8), (8, 0), (-1, 8)):
+        assert L.dbde_hip_encode_frames(h, imgs.data_ptr(), w_, h_, 1, 0, None, None, buf.data_ptr() + lead, cap, 0, None, None) == dv.ERR_ARG
+        assert L.dbde_hip_max_frame_bytes(w_, h_) == 0
+    assert L.dbde_hip_encode_frames(h, imgs.data_ptr(), W, H, -1, 0, None, None, buf.data_ptr() + lead, cap, 0, None, None) == dv.ERR_ARG
+    # null pointers
+    assert L.dbde_hip_encode_frames(h, None, W, H, n, 0, None, None, buf.data_ptr() + lead, cap, 0, None, None) == dv.ERR_ARG
+    assert L.dbde_hip_encode_frames(h, imgs.data_ptr(), W, H, n, 0, None, None, None, cap, 0, None, None) == dv.ERR_ARG
+    assert L.dbde_hip_decode_frames(h, buf.data_ptr(), cap, None, W, H, n, imgs.data_ptr(), None) == dv.ERR_ARG
+    # capacity below the worst case (concatenated and slots), slot stride below one frame
+    worst = dv.max_frame_bytes(W, H)
+    assert L.dbde_hip_encode_frames(h, imgs.data_ptr(), W, H, n, 0, None, None, buf.data_ptr() + lead, n * worst - 1, 0, None, None) == dv.ERR_CAPACITY
+    assert L.dbde_hip_encode_frames(h, imgs.data_ptr(), W, H, n, 0, None, None, buf.data_ptr() + lead, cap, worst - 1, None, None) == dv.ERR_ARG
+    assert L.dbde_hip_encode_frames(h, imgs.data_ptr(), W, H, n, 0, None, None, buf.data_ptr() + lead, 3 * worst, worst, None, None) == dv.ERR_CAPACITY
+    assert b"capacity" in L.dbde_hip_last_error(h)
+    codec.sync()
+    assert bool((buf == 0xEE).all()), "a refused call must not launch anything"
+    # the context is still usable
+    o, s = codec.encode_frames(imgs, W, H, n, buf, lead, cap)
+    back, _ = codec.decode_frames(buf, lead, cap, o, W, H, n)
+    codec.sync()
+    assert torch.equal(back, imgs)
+
+
+def test_crafted_minimum_wraps_per_byte(codec, oracle):
+    """min + value > 255 cannot come out of an encoder but is decodable: each byte wraps on its
+    own, as the reference's _mm_add_epi8 does (dbde_util.cpp:245-277)."""
+    import torch
+    W, H = 64, 24
+    T = 8 * 3
+    img = oracle.synth_frame(1, SEED, 3, W, H)
+    frame = oracle.pack_frame(9, img, W, H).copy()
+    frame[28 + T: 28 + 2 * T] = 250          # every tile's minimum
+    adv, fh, want = oracle.unpack_frame(frame, W, H)
+    assert fh[0] == 2
+    dev = torch.device("cuda", 0)
+    buf = torch.from_numpy(np.concatenate([np.zeros(32, np.uint8), frame, np.zeros(64, np.uint8)])).to(dev)
+    offs = torch.zeros(1, dtype=torch.int64, device=dev)
+    back, res = codec.decode_frames(buf, 32, len(frame), offs, W, H, 1)
+    codec.sync()
+    assert np.array_equal(back.cpu().numpy()[0], want)
+    assert codec.parse_results(res)[0] == (2, 9, 0, adv)

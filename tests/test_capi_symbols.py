@@ -73,5 +73,11 @@ def test_no_cpu_fallback():
         pytest.skip("a GPU is present")
     with pytest.raises(dv.DbdeError):
         dv.Codec(0)
-    src = open(os.path.join(ROOT, "dbde-video-cpp_amd", "__init__.py")).read()
-    assert "oracle" not in src.replace("oracle/synth.c", "").lower() or True
+    # and nothing in the product tree reaches for the oracle (test infrastructure only)
+    pkg = os.path.join(ROOT, "dbde-video-cpp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ("liboracle", "dbde_oracle", "oracle_ffi", "oracle/_ref", "libdbde_ref"):
+                    assert needle not in text, (f, needle)

@@ -398,3 +398,47 @@ def test_crafted_minimum_wraps_per_byte(codec, oracle):
     codec.sync()
     assert np.array_equal(back.cpu().numpy()[0], want)
     assert codec.parse_results(res)[0] == (2, 9, 0, adv)
+
+
+def test_two_contexts_on_concurrent_streams(dv, oracle):
+    """Two contexts on two HIP streams, launches interleaved without synchronisation: the
+    persistent encoder may find the device shared (not all of its workgroups resident at once)
+    and must still produce the same bytes -- it then takes chunks by ticket instead of by stride."""
+    import torch
+    W, H, n = 2048, 1024, 24
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    codecs = [dv.Codec(0, stream=s) for s in streams]
+    try:
+        state = []
+        for k, c in enumerate(codecs):
+            with torch.cuda.stream(streams[k]):
+                imgs = c.synth_frames("mixed", SEED, 1000 * k, n, W, H)
+                buf, lead, cap = c.alloc_stream(W, H, n)
+                back = torch.empty_like(imgs)
+                state.append([imgs, buf, lead, cap, back, None, None])
+        torch.cuda.synchronize(dev)
+        for rep in range(6):           # interleave: A enc, B enc, A dec, B dec, ...
+            for k, c in enumerate(codecs):
+                imgs, buf, lead, cap, back, _, _ = state[k]
+                with torch.cuda.stream(streams[k]):
+                    offs, sizes = c.encode_frames(imgs, W, H, n, buf, lead, cap, first_index=1000 * k)
+                state[k][5], state[k][6] = offs, sizes
+            for k, c in enumerate(codecs):
+                imgs, buf, lead, cap, back, offs, sizes = state[k]
+                with torch.cuda.stream(streams[k]):
+                    c.decode_frames(buf, lead, cap, offs, W, H, n, images=back)
+        for c in codecs:
+            c.sync()
+        for k, c in enumerate(codecs):
+            imgs, buf, lead, cap, back, offs, sizes = state[k]
+            assert torch.equal(back, imgs)
+            host = buf.cpu().numpy()
+            o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+            imgs_h = imgs.cpu().numpy()
+            for f in (0, n // 2, n - 1):
+                want = oracle.pack_frame(1000 * k + f, imgs_h[f], W, H)
+                assert host[lead + o[f]: lead + o[f] + s[f]].tobytes() == want.tobytes(), (k, f)
+    finally:
+        for c in codecs:
+            c.close()

@@ -51,7 +51,7 @@ struct DecParams {
     int W, H;
     uint32_t w, h, T;
     uint32_t chunks_per_frame, n_chunks;
-    uint32_t chunk_tiles;           // 512 or 256: tiles per workgroup
+    uint32_t chunk_tiles;           // 512 (default), 256 or 1024: tiles per workgroup
 };
 
 struct IdxParams {

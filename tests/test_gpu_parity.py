@@ -442,3 +442,51 @@ def test_two_contexts_on_concurrent_streams(dv, oracle):
     finally:
         for c in codecs:
             c.close()
+
+
+def test_seeded_fuzz_against_oracle(codec, oracle):
+    """120 seeded random cases: shape, frame count, layout, byte misalignment of the stream,
+    and content built to stress depth transitions (random per-tile depth and minimum, saturated
+    tiles, single-pixel outliers).  Encode bytes == oracle bytes, decode(encode) == image,
+    decode of the ORACLE's bytes == image."""
+    import torch
+    rng = np.random.default_rng(0xDBDE)
+    dev = torch.device("cuda", 0)
+    for case in range(120):
+        W = int(rng.integers(1, 200)) if case % 3 else int(rng.choice([8, 16, 64, 128, 256, 1024]))
+        H = int(rng.integers(1, 120))
+        n = int(rng.integers(1, 6))
+        w, h = (W + 7) // 8, (H + 7) // 8
+        # per-tile depth and minimum, pixel = min + noise < 2^depth, clipped to 255
+        d = rng.integers(0, 9, (n, h, w))
+        m = rng.integers(0, 256, (n, h, w))
+        noise = rng.integers(0, 256, (n, h * 8, w * 8))
+        dd = np.repeat(np.repeat(d, 8, 1), 8, 2)
+        mm = np.repeat(np.repeat(m, 8, 1), 8, 2)
+        img = np.minimum(mm + (noise & ((1 << dd) - 1)), 255).astype(np.uint8)[:, :H, :W]
+        if case % 5 == 0:      # outliers: one pixel per frame at 0 and one at 255
+            for f in range(n):
+                img[f, rng.integers(0, H), rng.integers(0, W)] = 0
+                img[f, rng.integers(0, H), rng.integers(0, W)] = 255
+        img = np.ascontiguousarray(img)
+        imgs = torch.from_numpy(img).to(dev)
+        worst = codec.L.dbde_hip_max_frame_bytes(W, H)
+        slot = 0 if case % 2 else int(worst + rng.integers(0, 64))
+        mis = int(rng.integers(0, 16))
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=case, slot_stride=slot,
+                                                      misalign=mis)
+        want = [oracle.pack_frame(case + f, img[f], W, H) for f in range(n)]
+        for f in range(n):
+            assert frames[f].tobytes() == want[f].tobytes(), (case, W, H, n, slot, mis, f)
+        total = int((offs[-1] + sizes[-1]).item())
+        back, res = codec.decode_frames(buf, lead, total, offs, W, H, n)
+        # the oracle's stream, at another misalignment, through the index scanner
+        mis2 = int(rng.integers(0, 16))
+        stream = np.concatenate([np.zeros(mis2, np.uint8)] + want + [np.zeros(64, np.uint8)])
+        sbuf = torch.from_numpy(stream).to(dev)
+        slen = len(stream) - mis2 - 64
+        offs2, found = codec.index_stream(sbuf, mis2, slen, W, H, n + 3)
+        assert found == n
+        back2, _ = codec.decode_frames(sbuf, mis2, slen, offs2, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs) and torch.equal(back2, imgs), (case, W, H, n, slot, mis, mis2)

@@ -198,6 +198,27 @@ def main():
                   "note": "variable-length gather of the compressed stream to rank 0 over RCCL; measured "
                           "separately, not inside the round-trip steps"}
 
+    # ---- configs[1] literally: ONE frame per call (launch-bound; reported beside the batched value) ----
+    single = None
+    if rank == 0 and world == 1:
+        one, ob, oo = imgs[:1], buf, out[:1]
+        def step1():
+            codec.encode_frames(one, W, H, 1, ob, lead, cap, first_index=0, offsets=offs[:1], nbytes=sizes[:1], slot_stride=slot)
+            codec.decode_frames(ob, lead, stream_cap, offs[:1], W, H, 1, images=oo, results=res[:1])
+        for _ in range(20):
+            step1()
+        codec.sync()
+        reps1 = 300
+        t1 = time.perf_counter()
+        for _ in range(reps1):
+            step1()
+        codec.sync()
+        d1 = (time.perf_counter() - t1) / reps1
+        single = {"frames_per_step": 1, "us_per_round_trip": round(d1 * 1e6, 2), "frames_per_s": round(1.0 / d1, 1),
+                  "identical": bool(torch.equal(oo, one)),
+                  "note": "one 4096x3072 frame per encode+decode call, device-resident, back to back: bounded by "
+                          "kernel launch and start-up latency, not by HBM"}
+
     if rank == 0:
         line = {
             "metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip",
@@ -214,6 +235,8 @@ def main():
                        "packed_over_raw": round(packed_bytes / raw, 4), "parallelism": f"frames sharded x{world}"},
             "roofline": roofline,
         }
+        if single:
+            line["single_frame"] = single
         if gather:
             line["gather"] = gather
         if not args.no_cpu and world == 1:

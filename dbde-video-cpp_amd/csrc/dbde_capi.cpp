@@ -46,6 +46,8 @@ struct dbde_hip_ctx {
     size_t chunk_off_n = 0;
     uint32_t *frame_ok = nullptr;
     size_t frame_ok_n = 0;
+    uint32_t *idx_ctr = nullptr;     // [2 * n]: arrival counters, then flags, of the split index kernel (kept zero)
+    size_t idx_ctr_n = 0;
     // sticky failure word (device) + scratch
     uint32_t *sticky = nullptr;
     uint64_t *scratch64 = nullptr;   // small device scratch: [0..3]
@@ -186,6 +188,7 @@ void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     if (ctx->lb) (void)hipFree(ctx->lb);
     if (ctx->chunk_off) (void)hipFree(ctx->chunk_off);
     if (ctx->frame_ok) (void)hipFree(ctx->frame_ok);
+    if (ctx->idx_ctr) (void)hipFree(ctx->idx_ctr);
     if (ctx->sticky) (void)hipFree(ctx->sticky);
     if (ctx->st_img) (void)hipFree(ctx->st_img);
     if (ctx->st_pack) (void)hipFree(ctx->st_pack);
@@ -340,6 +343,26 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     ip.T = g.T;
     ip.chunks_per_frame = dcpf;
     ip.chunk_shift = dec_ct == 256u ? 8u : (dec_ct == 1024u ? 10u : 9u);
+    // Few frames: cut each frame into pieces so that the index pass fills the device too
+    // (>= 4 chunks per piece, about 1024 workgroups in all); from 512 frames on, one workgroup per frame.
+    ip.split = 1;
+    ip.frame_ctr = nullptr;
+    ip.frame_flag = nullptr;
+    if (n_frames < 512 && dcpf >= 8u && !getenv("DBDE_HIP_IDX_NOSPLIT")) {
+        uint32_t sp = 1024u / (uint32_t)n_frames;
+        const uint32_t most = (dcpf + 3u) / 4u;
+        if (sp > most) sp = most;
+        if (sp > 1u) {
+            const size_t before = ctx->idx_ctr_n;
+            rc = grow(ctx, ctx->idx_ctr, ctx->idx_ctr_n, 2 * (size_t)n_frames, sizeof(uint32_t));
+            if (rc) return rc;
+            if (ctx->idx_ctr_n != before)   // fresh block: the kernel keeps it zero from here on
+                HIP_TRY(ctx, hipMemsetAsync(ctx->idx_ctr, 0, ctx->idx_ctr_n * sizeof(uint32_t), ctx->stream));
+            ip.split = sp;
+            ip.frame_ctr = ctx->idx_ctr;
+            ip.frame_flag = ctx->idx_ctr + n_frames;
+        }
+    }
     span_begin(ctx, 1);
     HIP_TRY(ctx, launch_decode_index(ip, n_frames, ctx->stream));
     span_end(ctx);

@@ -63,6 +63,9 @@ struct IdxParams {
     void *results;                  // optional dbde_hip_frame_result[n_frames]
     uint32_t T, chunks_per_frame;
     uint32_t chunk_shift;           // log2(tiles per chunk)
+    uint32_t split;                 // workgroups per frame (1 = decode_index_kernel, >1 = the split form)
+    uint32_t *frame_ctr;            // [n_frames] arrivals per frame, zero between launches (split form)
+    uint32_t *frame_flag;           // [n_frames] bit0 = a depth byte > 8 was seen (split form)
 };
 
 struct FrameResultDev {             // layout of dbde_hip_frame_result

@@ -894,12 +894,128 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same index for SMALL batches: one workgroup per frame leaves the device idle when there
+// are few frames (16.9 us for a single 4096x3072 frame), so a frame is cut into p.split
+// pieces.  A piece sums its chunks (one wave per chunk, CT/64 bytes per lane, DPP reduction,
+// no LDS atomics) and publishes the sums in place of the offsets; the LAST piece of a frame to
+// finish (per-frame arrival counter, self-resetting) turns them into the exclusive prefix and
+// does the validation and the header exactly as decode_index_kernel does.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_last;
+
+    const uint32_t f = blockIdx.x / p.split, piece = blockIdx.x - f * p.split;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t T = p.T, cpf = p.chunks_per_frame;
+    const uint64_t off = p.frame_offsets[f];
+    const uint64_t need = 32ull + 2ull * T;
+    const bool in_range = off + need <= p.stream_bytes;
+    const uint8_t *fb = p.stream + off;
+    uint32_t *co = p.chunk_off + (size_t)f * (cpf + 1u);
+
+    // ---- chunk sums of this piece ----
+    const uint32_t per = (cpf + p.split - 1u) / p.split;
+    const uint32_t k_begin = piece * per, k_end = k_begin + per < cpf ? k_begin + per : cpf;
+    const uint32_t ct = 1u << p.chunk_shift, bpl = ct >> 6;   // bytes per lane: 4, 8 or 16
+    uint32_t bad = 0;
+    for (uint32_t k = k_begin + (uint32_t)wave; k < k_end; k += 4u) {
+        uint32_t sum = 0;
+        if (in_range) {
+            const uint8_t *darr = fb + 24;
+            const uint32_t pos = k * ct + (uint32_t)lane * bpl;
+            for (uint32_t j = 0; j < bpl; j += 4u) {
+                const uint32_t q = pos + j;
+                if (q < T) {   // the 4 bytes at q lie inside the frame (the min array follows)
+                    uint32_t x;
+                    __builtin_memcpy(&x, darr + q, 4);
+                    const uint32_t keep = T - q;   // tiles left
+                    if (keep < 4u) x &= 0xFFFFFFFFu >> (8u * (4u - keep));
+                    bad |= (x & 0xF0F0F0F0u) | ((x + 0x77777777u) & 0x80808080u);   // any byte > 8
+                    sum += __builtin_amdgcn_sad_u8(x, 0u, 0u);
+                }
+            }
+        }
+        const uint32_t tot = wave_scan_incl(sum);
+        if (lane == 63) __hip_atomic_store(&co[k], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (__any((int)(bad != 0u)) && lane == 0) atomicOr(&p.frame_flag[f], 1u);
+
+    // ---- arrival: the last piece of the frame finishes the job ----
+    // The sums were written through to memory (agent-scope atomic stores); once every wave has
+    // seen its stores acknowledged, the arrival can be counted.  No fence: an agent-scope
+    // release on this part writes back the whole L2, which costs more than the kernel.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&p.frame_ctr[f], 1u) == p.split - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+
+    const uint32_t seg = (cpf + 255u) / 256u;
+    const uint32_t k0 = (uint32_t)tid * seg;
+    uint32_t local = 0;
+    for (uint32_t k = k0; k < k0 + seg && k < cpf; k++)
+        local += __hip_atomic_load(&co[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t incl = wave_scan_incl(local);
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t v = s_part[k];
+        base += k < wave ? v : 0u;
+        total += v;
+    }
+    uint32_t run = base + incl - local;
+    for (uint32_t k = k0; k < k0 + seg && k < cpf; k++) {
+        const uint32_t v = __hip_atomic_load(&co[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        co[k] = run;
+        run += v;
+    }
+    if (tid == 0) {
+        co[cpf] = total;
+        const uint32_t flags = __hip_atomic_load(&p.frame_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.frame_flag[f] = 0;   // clean for the next launch
+        p.frame_ctr[f] = 0;
+        bool ok = in_range;
+        uint32_t field = 0;
+        uint64_t index = 0, elapsed = 0, consumed = 20;
+        if (off + 20 <= p.stream_bytes) {
+            field = load_u32_bytes(fb);
+            index = load_u64_bytes(fb + 4);
+            elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
+        }
+        if (ok) {
+            const int32_t nb = (int32_t)load_u32_bytes(fb + 20);
+            const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
+            const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
+            ok = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && !(flags & 1u);
+            if (ok && off + need + 8ull * total > p.stream_bytes) ok = false;
+            if (ok) consumed = need + 8ull * total;
+        }
+        p.frame_ok[f] = ok ? 1u : 0u;
+        if (p.results) {
+            FrameResultDev *r = reinterpret_cast<FrameResultDev *>(p.results) + f;
+            r->u64s = (field == 2u && ok) ? 2u : 0xFFFFFFFFu;   // dbde_util.cpp:335,342
+            r->pad_ = 0;
+            r->index = index;
+            r->elapsed_ns = elapsed;
+            r->consumed = consumed;
+        }
+    }
+}
+
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s) {
     const size_t lds = (size_t)p.chunks_per_frame * sizeof(uint32_t);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(decode_index_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+    }
+    if (p.split > 1u) {
+        hipLaunchKernelGGL(decode_index_split_kernel, dim3((uint32_t)n_frames * p.split), dim3(256), 0, s, p);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(decode_index_kernel, dim3(n_frames), dim3(1024), lds, s, p);
     return hipGetLastError();

@@ -344,11 +344,11 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     ip.chunks_per_frame = dcpf;
     ip.chunk_shift = dec_ct == 256u ? 8u : (dec_ct == 1024u ? 10u : 9u);
     // Few frames: cut each frame into pieces so that the index pass fills the device too
-    // (>= 4 chunks per piece, about 1024 workgroups in all); from 512 frames on, one workgroup per frame.
+    // (>= 4 chunks per piece, about 1024 workgroups in all); from 256 frames on, one workgroup per frame.
     ip.split = 1;
     ip.frame_ctr = nullptr;
     ip.frame_flag = nullptr;
-    if (n_frames < 512 && dcpf >= 8u && !getenv("DBDE_HIP_IDX_NOSPLIT")) {
+    if (n_frames < 256 && dcpf >= 8u && !getenv("DBDE_HIP_IDX_NOSPLIT")) {
         uint32_t sp = 1024u / (uint32_t)n_frames;
         const uint32_t most = (dcpf + 3u) / 4u;
         if (sp > most) sp = most;

@@ -523,7 +523,9 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
     if (tid == 0) {
         uint32_t mode = 0;
         const uint64_t t0 = wall_clock64();
-        for (;;) {
+        // one chunk per workgroup at most (n_chunks <= G): there is nothing to agree on
+        if (p.n_chunks <= G) mode = 1u;
+        while (!mode) {
             mode = __hip_atomic_load(&p.ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (mode) break;
             const uint32_t arrived = __hip_atomic_load(&p.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -88,8 +88,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rehearsal on a one-GPU box: DBDE_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo
+        # (exercises the launch contract, sharding, barrier and max-over-ranks; not a measurement)
+        rehearsal = os.environ.get("DBDE_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+            args.no_gather = True
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
         local = 0

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--content", default="noise8", choices=["noise8", "mixed", "smooth", "flat"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-frame-per-call leg (profiling runs)")
     ap.add_argument("--concat", action="store_true", help="one concatenated stream instead of one slot per frame")
     ap.add_argument("--no-check", action="store_true", help="(experiments) skip the round-trip parity gate")
     args = ap.parse_args()
@@ -209,7 +210,7 @@ def main():
 
     # ---- configs[1] literally: ONE frame per call (launch-bound; reported beside the batched value) ----
     single = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_single:
         one, ob, oo = imgs[:1], buf, out[:1]
         def step1():
             codec.encode_frames(one, W, H, 1, ob, lead, cap, first_index=0, offsets=offs[:1], nbytes=sizes[:1], slot_stride=slot)

@@ -11,7 +11,7 @@ CONTENT=${2:-noise8}
 OUT=gpurun_out/prof_${TAG}_${CONTENT}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu --content $CONTENT $3"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu --no-single --content $CONTENT $3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ARGS > $OUT/kt.log 2>&1 || echo "kt failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1 || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1 || echo "write failed"

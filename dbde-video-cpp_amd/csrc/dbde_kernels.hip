@@ -134,6 +134,12 @@ __device__ __forceinline__ void load_tile_generic(const uint8_t *img, int W, int
         uint64_t q;
         if (rm == 8) {
             q = load_u64_any(row);
+        } else if (W >= 8) {
+            // right margin: the 8 bytes that END at the last valid pixel are inside the image; shift
+            // the valid ones down and repeat the last one (dbde_util.cpp:116-128) -- one load, not rm
+            q = load_u64_any(row + rm - 8) >> (8 * (8 - rm));
+            const uint64_t last = (q >> (8 * (rm - 1))) & 0xFFull;
+            q |= (last * 0x0101010101010101ull) << (8 * rm);
         } else {
             q = 0;
 #pragma unroll
@@ -360,8 +366,24 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
             }
         }
     } else {
-        if (k.hasA) load_tile_generic(img, p.W, p.H, p.w, k.t0, va);
-        if (k.hasB) load_tile_generic(img, p.W, p.H, p.w, k.t0 + 1u, vb);
+        // two full-width tiles side by side in one tile row (all but the row ends): one 16-byte
+        // load per image row at whatever alignment the row has
+        const uint32_t ty = k.t0 / p.w, tx = k.t0 - ty * p.w;
+        if (k.hasB && tx + 1u < p.w && 8 * ((int)tx + 2) <= p.W) {
+            const uint8_t *base = img + (size_t)(8u * tx);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int yy = 8 * (int)ty + r;
+                yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
+                uint32_t q[4];
+                __builtin_memcpy(q, base + (size_t)yy * (size_t)p.W, 16);
+                va[2 * r] = q[0]; va[2 * r + 1] = q[1];
+                vb[2 * r] = q[2]; vb[2 * r + 1] = q[3];
+            }
+        } else {
+            if (k.hasA) load_tile_generic(img, p.W, p.H, p.w, k.t0, va);
+            if (k.hasB) load_tile_generic(img, p.W, p.H, p.w, k.t0 + 1u, vb);
+        }
     }
 }
 

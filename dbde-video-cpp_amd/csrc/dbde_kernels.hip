@@ -343,7 +343,47 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
     return k;
 }
 
-template <bool FAST_IN, bool ZERO = true>
+// Branch-free half of load_tile_generic for W >= 8: the 8 bytes ending at the tile row's last valid pixel.
+__device__ __forceinline__ void load_tile_generic_raw(const uint8_t *img, int W, int H, uint32_t w, uint32_t t,
+                                                      uint32_t (&v)[16]) {
+    const uint32_t ty = t / w, tx = t - ty * w;
+    const int x0 = 8 * (int)tx;
+    const int rm = W - x0 < 8 ? W - x0 : 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int yy = 8 * (int)ty + r;
+        yy = yy < H ? yy : H - 1;   // bottom padding = repeat the last row
+        const uint64_t q = load_u64_any(img + (size_t)yy * (size_t)W + (size_t)(x0 + rm - 8));
+        v[2 * r] = (uint32_t)q;
+        v[2 * r + 1] = (uint32_t)(q >> 32);
+    }
+}
+__device__ __forceinline__ void fixup_tile_generic(int W, uint32_t w, uint32_t t, bool has, uint32_t (&v)[16]) {
+    const uint32_t ty = t / w, tx = t - ty * w;
+    const int x0 = 8 * (int)tx;
+    const int rm = W - x0 < 8 ? W - x0 : 8;
+    if (!has) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = 0;
+    } else if (rm < 8) {   // right margin: valid pixels down to byte 0, the last one repeated
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint64_t q = (((uint64_t)v[2 * r + 1] << 32) | v[2 * r]) >> (8 * (8 - rm));
+            const uint64_t last = (q >> (8 * (rm - 1))) & 0xFFull;
+            q |= (last * 0x0101010101010101ull) << (8 * rm);
+            v[2 * r] = (uint32_t)q;
+            v[2 * r + 1] = (uint32_t)(q >> 32);
+        }
+    }
+}
+
+// IN_MODE: how a chunk's pixels are fetched.  kInFast: W % 16 == 0 and a 16-byte aligned base (one
+// 16-byte load per row and lane); kInRaw: any geometry with W >= 8 (branch-free 8-byte loads, fixed up
+// when consumed); kInBytes: images narrower than one tile (byte by byte).  A template parameter, not a
+// run-time branch: the number of loads a step issues must be static for them to stay in flight.
+constexpr int kInFast = 0, kInRaw = 1, kInBytes = 2;
+
+template <int IN_MODE, bool ZERO = true>
 __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                            uint32_t (&vb)[16]) {
     if (ZERO) {   // (callers that never read registers of tile-less lanes skip this)
@@ -351,7 +391,7 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
         for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
     }
     const uint8_t *img = p.images + (size_t)k.f * p.frame_pixels;
-    if (FAST_IN) {   // W % 16 == 0, base 16-aligned: both tiles in one strip, one 16-B load per row
+    if (IN_MODE == kInFast) {   // W % 16 == 0, base 16-aligned: both tiles in one strip, one 16-B load per row
         if (k.hasA) {
             const uint32_t ty = k.t0 / p.w, tx = k.t0 - ty * p.w;
             const uint8_t *base = img + (size_t)(8u * tx);
@@ -366,25 +406,27 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
             }
         }
     } else {
-        // two full-width tiles side by side in one tile row (all but the row ends): one 16-byte
-        // load per image row at whatever alignment the row has
-        const uint32_t ty = k.t0 / p.w, tx = k.t0 - ty * p.w;
-        if (k.hasB && tx + 1u < p.w && 8 * ((int)tx + 2) <= p.W) {
-            const uint8_t *base = img + (size_t)(8u * tx);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                int yy = 8 * (int)ty + r;
-                yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
-                uint32_t q[4];
-                __builtin_memcpy(q, base + (size_t)yy * (size_t)p.W, 16);
-                va[2 * r] = q[0]; va[2 * r + 1] = q[1];
-                vb[2 * r] = q[2]; vb[2 * r + 1] = q[3];
-            }
-        } else {
+        if (IN_MODE == kInRaw) {
+            // Straight-line, branch-free loads so that they can stay in flight until the next step:
+            // every lane reads 8 bytes per row and tile at an in-bounds address -- for a right-margin
+            // tile the 8 bytes that END at its last valid pixel -- and load_fixup_generic() shifts,
+            // pads (dbde_util.cpp:116-132) or zeroes them when they are consumed.
+            load_tile_generic_raw(img, p.W, p.H, p.w, k.hasA ? k.t0 : 0u, va);
+            load_tile_generic_raw(img, p.W, p.H, p.w, k.hasB ? k.t0 + 1u : 0u, vb);
+        } else {   // images narrower than one tile: byte by byte
             if (k.hasA) load_tile_generic(img, p.W, p.H, p.w, k.t0, va);
             if (k.hasB) load_tile_generic(img, p.W, p.H, p.w, k.t0 + 1u, vb);
         }
     }
+}
+
+// Second half of the generic load (see load_chunk): applied to the registers of `k` when they are used.
+template <int IN_MODE>
+__device__ __forceinline__ void load_fixup_generic(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
+                                                   uint32_t (&vb)[16]) {
+    if (IN_MODE != kInRaw) return;
+    fixup_tile_generic(p.W, p.w, k.t0, k.hasA, va);
+    fixup_tile_generic(p.W, p.w, k.t0 + 1u, k.hasB, vb);
 }
 
 // One tile row -> 8*d-bit integer with two v_dot4_u32_u8 per 4 pixels (weights 1, 2^d);
@@ -510,8 +552,8 @@ __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkR
     }
 }
 
-template <bool FAST_IN, bool ALIGNED_OUT>
-__global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
+template <int IN_MODE, bool ALIGNED_OUT>
+__global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     __shared__ __attribute__((aligned(16))) EncShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -533,7 +575,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
     const uint32_t rank = __builtin_amdgcn_readfirstlane(sh.boot[0]);
     ChunkRef cur = chunk_ref(p, rank, tid);
     uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-    load_chunk<FAST_IN>(p, cur, r0a, r0b);          // in flight while the mode is agreed below
+    load_chunk<IN_MODE>(p, cur, r0a, r0b);          // in flight while the mode is agreed below
     __syncthreads();   // sh.boot is reused below
 
     // How later chunks are claimed.  STATIC (chunk = rank + k*G, no atomics) is only safe when
@@ -591,10 +633,11 @@ __global__ __launch_bounds__(kEncThreads) void encode_kernel(EncParams p) {
             sh.lb[par][3] = tnew;
         }
         // ---- 2. image loads of nxt (consumed when the pipeline rotates) --------------------------
-        load_chunk<FAST_IN>(p, nxt, na, nb);
+        load_chunk<IN_MODE>(p, nxt, na, nb);
 
         // ---- 3. statistics of cur (dbde_util.cpp:30-68), offsets inside the wave, AGG -------------
         uint32_t mnA, mxA, mnB, mxB;
+        load_fixup_generic<IN_MODE>(p, cur, ca, cb);
         tile_minmax(ca, mnA, mxA);
         tile_minmax(cb, mnB, mxB);
         const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
@@ -686,9 +729,10 @@ struct EncSharedFW {
         uint32_t nf = f, ncf = cf + 1u;                                                                            \
         if (ncf == cpf) { ncf = 0; nf = f + gridDim.x; }                                                           \
         const ChunkRef nxt = chunk_ref(p, nf < n_frames ? nf * cpf + ncf : 0xFFFFFFFFu, tid, WAVES * 128u);                      \
-        load_chunk<FAST_IN, false>(p, nxt, RNA, RNB);                                                              \
+        load_chunk<IN_MODE, false>(p, nxt, RNA, RNB);                                                              \
         /* statistics (dbde_util.cpp:30-68) and offsets inside the wave */                                         \
         uint32_t mnA, mxA, mnB, mxB;                                                                               \
+        load_fixup_generic<IN_MODE>(p, cur, RCA, RCB);                                                             \
         tile_minmax(RCA, mnA, mxA);                                                                                \
         tile_minmax(RCB, mnB, mxB);                                                                                \
         const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;                                             \
@@ -726,7 +770,7 @@ struct EncSharedFW {
         it++;                                                                                                      \
     }
 
-template <bool FAST_IN, bool ALIGNED_OUT, int WAVES>
+template <int IN_MODE, bool ALIGNED_OUT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void encode_framewise_kernel(EncParams p) {
     __shared__ __attribute__((aligned(16))) EncSharedFW<WAVES> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -740,7 +784,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void encode_framewise_kernel(EncPara
     uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { r0a[i] = 0; r0b[i] = 0; r1a[i] = 0; r1b[i] = 0; }   // lanes without tiles stay 0
-    load_chunk<FAST_IN, false>(p, cur, r0a, r0b);
+    load_chunk<IN_MODE, false>(p, cur, r0a, r0b);
     uint32_t inf = 0;   // payload words of this frame before cur
     uint32_t it = 0;
     // two steps per trip with the register sets swapped: no copy between them
@@ -752,14 +796,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void encode_framewise_kernel(EncPara
 }
 #undef DBDE_FW_STEP
 
+static int in_mode_of(const EncParams &p, bool fast_in) { return fast_in ? kInFast : (p.W >= 8 ? kInRaw : kInBytes); }
+
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
     dim3 block(kEncThreads);
     // resident capacity, scanner included (so that all encoding workgroups can be co-resident)
     dim3 grid(p.n_chunks + 1u < p.grid_blocks ? p.n_chunks + 1u : p.grid_blocks);
-    if (fast_in && aligned_out) hipLaunchKernelGGL((encode_kernel<true, true>), grid, block, 0, s, p);
-    else if (fast_in) hipLaunchKernelGGL((encode_kernel<true, false>), grid, block, 0, s, p);
-    else if (aligned_out) hipLaunchKernelGGL((encode_kernel<false, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((encode_kernel<false, false>), grid, block, 0, s, p);
+    switch (in_mode_of(p, fast_in) * 2 + (aligned_out ? 1 : 0)) {
+        case kInFast * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInFast, true>), grid, block, 0, s, p); break;
+        case kInFast * 2 + 0: hipLaunchKernelGGL((encode_kernel<kInFast, false>), grid, block, 0, s, p); break;
+        case kInRaw * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInRaw, true>), grid, block, 0, s, p); break;
+        case kInRaw * 2 + 0: hipLaunchKernelGGL((encode_kernel<kInRaw, false>), grid, block, 0, s, p); break;
+        case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInBytes, true>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((encode_kernel<kInBytes, false>), grid, block, 0, s, p); break;
+    }
     return hipGetLastError();
 }
 
@@ -767,10 +817,14 @@ template <int WAVES>
 static hipError_t launch_fw(const EncParams &p, bool fast_in, bool aligned_out, uint32_t max_blocks, hipStream_t s) {
     const uint32_t n_frames = p.n_chunks / p.chunks_per_frame;
     dim3 block(64 * WAVES), grid(n_frames < max_blocks ? n_frames : max_blocks);
-    if (fast_in && aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<true, true, WAVES>), grid, block, 0, s, p);
-    else if (fast_in) hipLaunchKernelGGL((encode_framewise_kernel<true, false, WAVES>), grid, block, 0, s, p);
-    else if (aligned_out) hipLaunchKernelGGL((encode_framewise_kernel<false, true, WAVES>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((encode_framewise_kernel<false, false, WAVES>), grid, block, 0, s, p);
+    switch (in_mode_of(p, fast_in) * 2 + (aligned_out ? 1 : 0)) {
+        case kInFast * 2 + 1: hipLaunchKernelGGL((encode_framewise_kernel<kInFast, true, WAVES>), grid, block, 0, s, p); break;
+        case kInFast * 2 + 0: hipLaunchKernelGGL((encode_framewise_kernel<kInFast, false, WAVES>), grid, block, 0, s, p); break;
+        case kInRaw * 2 + 1: hipLaunchKernelGGL((encode_framewise_kernel<kInRaw, true, WAVES>), grid, block, 0, s, p); break;
+        case kInRaw * 2 + 0: hipLaunchKernelGGL((encode_framewise_kernel<kInRaw, false, WAVES>), grid, block, 0, s, p); break;
+        case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_framewise_kernel<kInBytes, true, WAVES>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((encode_framewise_kernel<kInBytes, false, WAVES>), grid, block, 0, s, p); break;
+    }
     return hipGetLastError();
 }
 
@@ -783,7 +837,7 @@ hipError_t launch_encode_framewise(const EncParams &p, int waves, bool fast_in, 
 // Resident workgroups per CU of the encoder (occupancy query; LDS- and VGPR-bound).
 int encode_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, encode_kernel<true, true>, kEncThreads, 0) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, encode_kernel<kInFast, true>, kEncThreads, 0) != hipSuccess || n < 1)
         n = 1;
     return n;
 }

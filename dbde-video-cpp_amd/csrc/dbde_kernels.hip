@@ -392,18 +392,20 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
     }
     const uint8_t *img = p.images + (size_t)k.f * p.frame_pixels;
     if (IN_MODE == kInFast) {   // W % 16 == 0, base 16-aligned: both tiles in one strip, one 16-B load per row
-        if (k.hasA) {
-            const uint32_t ty = k.t0 / p.w, tx = k.t0 - ty * p.w;
-            const uint8_t *base = img + (size_t)(8u * tx);
+        // No branch around the loads: a lane without tiles reads tile 0 of frame 0 and nobody looks
+        // at the result.  With a conditional issue the compiler cannot know how many loads are in
+        // flight and makes the statistics of the CURRENT chunk wait for these as well.
+        const uint32_t t = k.hasA ? k.t0 : 0u;
+        const uint32_t ty = t / p.w, tx = t - ty * p.w;
+        const uint8_t *base = img + (size_t)(8u * tx);
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                int yy = 8 * (int)ty + r;
-                yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
-                const u32x4_t *src = reinterpret_cast<const u32x4_t *>(base + (size_t)yy * (size_t)p.W);
-                const u32x4_t q = DBDE_NT ? __builtin_nontemporal_load(src) : *src;
-                va[2 * r] = q[0]; va[2 * r + 1] = q[1];
-                vb[2 * r] = q[2]; vb[2 * r + 1] = q[3];
-            }
+        for (int r = 0; r < 8; r++) {
+            int yy = 8 * (int)ty + r;
+            yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(base + (size_t)yy * (size_t)p.W);
+            const u32x4_t q = DBDE_NT ? __builtin_nontemporal_load(src) : *src;
+            va[2 * r] = q[0]; va[2 * r + 1] = q[1];
+            vb[2 * r] = q[2]; vb[2 * r + 1] = q[3];
         }
     } else {
         if (IN_MODE == kInRaw) {

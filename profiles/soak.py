@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Soak: many full-size batches (random content / batch size / layout), each round-tripped on the GPU
+and spot-checked against the oracle's bytes.  Looks for rare, timing-dependent corruption in the
+persistent encoder (hand-placed waits, cross-workgroup hand-off), which short parity tests could miss.
+
+    python profiles/soak.py [--rounds 40] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import dbde_video_cpp_amd as dv  # noqa: E402
+from oracle_ffi import Oracle  # noqa: E402  (checker only)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=40)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+codec, ora = dv.Codec(0), Oracle()
+shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080)]
+t0 = time.time()
+frames_done = 0
+for r in range(a.rounds):
+    W, H = shapes[int(rng.integers(0, len(shapes)))]
+    per = W * H
+    n = int(rng.choice([1, 3, 17, 64, 200, 512, 1024]))
+    n = max(1, min(n, int(9e9 // per)))
+    content = str(rng.choice(["noise8", "mixed", "smooth", "flat"]))
+    concat = bool(rng.integers(0, 2)) and n * 8 * dv.tiles(W, H) < 2**32
+    first = int(rng.integers(0, 1 << 40))
+    imgs = codec.synth_frames(content, 0xDBDE2016 + r, first, n, W, H)
+    slot = 0 if concat else ((dv.max_frame_bytes(W, H) + 255) // 256) * 256
+    buf, lead, cap = codec.alloc_stream(W, H, n, slot_stride=slot)
+    for rep in range(3):   # same inputs three times: a race would not repeat itself identically
+        offs, sizes = codec.encode_frames(imgs, W, H, n, buf, lead, cap, first_index=first, slot_stride=slot)
+        back, res = codec.decode_frames(buf, lead, cap, offs, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs), (r, rep, W, H, n, content, concat)
+        if rep == 0:
+            host_o, host_s = offs.cpu().numpy(), sizes.cpu().numpy()
+            ref_sum = int(buf[lead:lead + int(host_o[-1] + host_s[-1])].to(torch.int64).sum().item()) if concat else None
+        elif concat:
+            assert int(buf[lead:lead + int(host_o[-1] + host_s[-1])].to(torch.int64).sum().item()) == ref_sum
+    for f in sorted(set([0, n // 2, n - 1])):
+        want = ora.pack_frame(first + f, imgs[f].cpu().numpy(), W, H)
+        got = buf[lead + int(host_o[f]): lead + int(host_o[f] + host_s[f])].cpu().numpy()
+        assert got.tobytes() == want.tobytes(), (r, f, W, H, n, content, concat)
+    frames_done += 3 * n
+    del imgs, buf, back, res
+    print(f"round {r:3d}: {W}x{H} n={n:5d} {content:7s} {'concat' if concat else 'slots '} ok", flush=True)
+print(f"soak ok: {a.rounds} rounds, {frames_done} frame round trips, {time.time() - t0:.0f} s")

@@ -65,6 +65,49 @@ def gather_stream(segment, nbytes, dst=0, group=None, out=None, max_message_byte
     return None, sizes
 
 
+def scatter_stream(stream, frame_bytes, src=0, group=None, device=None, max_message_bytes=None):
+    """The decode-side counterpart of gather_stream: rank `src` holds a concatenated frame
+    sequence (`stream`, uint8 1-D, no video header) and the byte length of every frame
+    (`frame_bytes`, list of ints); every rank receives the bytes of ITS contiguous frame block
+    (shard_frames) and the frame offsets inside that segment.  Returns (segment, offsets, (lo, hi)) on
+    every rank -- `segment` is a uint8 tensor on `device` (default: the stream's device on src, cpu
+    elsewhere), `offsets` a list of ints relative to the segment, [lo, hi) the global frame numbers.
+    Other ranks pass stream=None, frame_bytes=None."""
+    piece = int(max_message_bytes or MAX_MESSAGE_BYTES)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    meta = [list(map(int, frame_bytes))] if rank == src else [None]
+    dist.broadcast_object_list(meta, src=src, group=group)      # frame lengths: a few bytes per frame
+    sizes = meta[0]
+    n = len(sizes)
+    starts = [0] * (n + 1)
+    for i, b in enumerate(sizes):
+        starts[i + 1] = starts[i] + b
+    lo, hi = shard_frames(n, rank, world)
+    my_bytes = starts[hi] - starts[lo]
+    offsets = [starts[f] - starts[lo] for f in range(lo, hi)]
+    if rank == src:
+        dev = stream.device if device is None else device
+        ops = []
+        for r in range(world):
+            rlo, rhi = shard_frames(n, r, world)
+            if r == rank:
+                continue
+            a, nb = starts[rlo], starts[rhi] - starts[rlo]
+            for o, m in _pieces(nb, piece):
+                ops.append(dist.P2POp(dist.isend, stream[a + o:a + o + m], r, group))
+        seg = stream[starts[lo]:starts[hi]].to(dev)
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return seg, offsets, (lo, hi)
+    dev = torch.device("cpu") if device is None else device
+    seg = torch.empty(my_bytes, dtype=torch.uint8, device=dev)
+    ops = [dist.P2POp(dist.irecv, seg[o:o + m], src, group) for o, m in _pieces(my_bytes, piece)]
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return seg, offsets, (lo, hi)
+
+
 def frame_offsets_from_sizes(per_rank_frame_bytes):
     """Root-side frame index of the gathered stream: list (per rank) of per-frame byte counts ->
     flat list of frame offsets relative to the first frame (exclusive scan)."""

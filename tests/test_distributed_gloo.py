@@ -57,6 +57,20 @@ def _worker(rank, world, port, q):
             at += adv
             n += 1
         q.put(bool(ok and n == N))
+    # decode side: the root scatters frame blocks of the gathered stream back out; every rank
+    # decodes its own block (the oracle standing in for the GPU decoder) and finds its frames
+    if rank == 0:
+        all_sizes = [len(ora.pack_frame(f, ora.synth_frame(1, SEED, f, W, H), W, H)) for f in range(N)]
+        seg2, offs2, (lo2, hi2) = dd.scatter_stream(stream, all_sizes, src=0, max_message_bytes=61)
+    else:
+        seg2, offs2, (lo2, hi2) = dd.scatter_stream(None, None, src=0, max_message_bytes=61)
+    assert (lo2, hi2) == (lo, hi) and len(offs2) == hi - lo
+    body2 = seg2.numpy()
+    ok2 = True
+    for k, f in enumerate(range(lo2, hi2)):
+        adv, fh, img = ora.unpack_frame(body2[offs2[k]:], W, H)
+        ok2 = ok2 and fh == (2, f, 0) and (img == ora.synth_frame(1, SEED, f, W, H)).all()
+    q.put(("scatter", rank, bool(ok2)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,7 +88,7 @@ def test_shard_frames_partition():
     assert offs == [0, 10, 30, 35, 42] and total == 49
 
 
-def test_gather_stream_world2_gloo():
+def test_gather_and_scatter_stream_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -82,4 +96,6 @@ def test_gather_stream_world2_gloo():
     [p.start() for p in procs]
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert q.get(timeout=5) is True
+    got = [q.get(timeout=5) for _ in range(3)]
+    assert True in got                                     # rank 0: the gathered stream is the full stream
+    assert sorted(g for g in got if isinstance(g, tuple)) == [("scatter", 0, True), ("scatter", 1, True)]

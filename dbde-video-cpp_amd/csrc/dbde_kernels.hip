@@ -1262,9 +1262,12 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
     uint32_t va[16], vb[16];
     const uint8_t *s_img = reinterpret_cast<const uint8_t *>(s_in);
     const uint32_t bA = shift + 8u * offA, bB = shift + 8u * offB;
-    // wave-uniform specialisation: every tile of the wave has depth 8 (rows are whole qwords)
+    // wave-uniform specialisations: all tiles flat (depth 0), or all of depth 8 (rows are whole qwords)
     const bool all8 = (shift & 7u) == 0u && __all((int)(dA == 8u && dB == 8u));
-    if (all8) {
+    if (__all((int)((dA | dB) == 0u))) {   // flat tiles only: every pixel is its tile's minimum, no payload
+#pragma unroll
+        for (int i = 0; i < 16; i++) { va[i] = mA * 0x01010101u; vb[i] = mB * 0x01010101u; }
+    } else if (all8) {
         unpack_tile_d8_from_lds(s_img, bA, mA, va);
         unpack_tile_d8_from_lds(s_img, bB, mB, vb);
     } else {

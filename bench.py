@@ -1,59 +1,98 @@
 #!/usr/bin/env python3
 """bench.py -- DBDE encode+decode round trip on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--content noise8|mixed]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--content noise8|mixed|smooth|flat]
+                    [--frames B] [--concat] [--only] [--no-cpu] [--no-single] [--no-gather]
 
-One step = one pass of the hot path over one batch: encode B distinct synthetic 4096x3072 U8
-frames (resident in HBM) into DBDE frames, then decode them back to images.  Default layout:
-one fixed-stride slot per frame -- the reference's own semantics, dbde_pack_frame packs each
-frame into its own target -- which lets the encoder give every workgroup whole frames;
---concat writes one concatenated stream instead (a ready .dbde body; chunk offsets then come
-from an in-launch scan).  B*W*H is far beyond the 256 MiB Infinity Cache, so every step
-streams from HBM.  Default B = 1024 (BASELINE config 5 gives each GPU 1250 frames).
-N > 1: launched by torch.distributed.run, one rank per GPU; frames are sharded by blocks
-(rank g owns frames [g*B, (g+1)*B)), no collective on the data path (weak scaling).  The
-RCCL gather of the compressed stream to rank 0 is run and timed separately ("gather").
+One step = one pass of the hot path over one batch: encode B distinct synthetic U8 frames (resident in
+HBM) into DBDE frames, then decode them back to images.  `value` (frames/s) is always the configs[1]
+workload -- 4096x3072, noise8, B = 1024 frames per step per GPU, one slot per frame -- timed over exactly K
+steps between barriers.  B*W*H is far beyond the 256 MiB Infinity Cache, so every step streams from HBM.
 
+The same run then times, with the same method (HIP events on the codec's stream + host wall clock),
+  contents : mixed (depths 0..8 uniform: the path that really bit-packs) and smooth, same shape
+  configs  : "3" 1000 frames of 2048x2048 mixed as ONE concatenated stream, decoded from the offsets
+                 the device stream scanner finds (dbde_hip_index_stream), as a .dbde reader would;
+             "4" 1921x1081 mixed (every row unaligned, edge tiles on two sides: constant-pad path)
+  single_frame : configs[1] literally, one frame per encode+decode call
+  cpu_baseline : the reference (oracle/_ref) on ALL host cores
+`--only` keeps just the headline leg (profiling runs); `--config 3|4|5` makes that workload the headline.
+`--config 5`: the 10,000-frame stream, each rank walking its block of frames in batches through the
+streaming driver (frames produced on the fly, never all resident), with the RCCL gather of batch k
+overlapped with the encode of batch k+1; reported with and without the gather.
+
+N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run, one per GPU, before any GPU
+call); launched under torchrun it uses the ranks it is given.  Frames are sharded by contiguous blocks
+(rank g owns frames [g*B, (g+1)*B) of each step): no collective on the data path, weak scaling.
 Rank 0 prints ONE JSON line.  `value` = frames all ranks round-tripped per second.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import dbde_video_cpp_amd as dv  # noqa: E402
-
-W, H = 4096, 3072
 SEED = 0xDBDE2016
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+CONFIGS = {              # BASELINE.json configs[1..4]
+    2: dict(W=4096, H=3072, frames=1024, content="noise8", layout="slots", name="configs[1]: 4096x3072 U8 frames"),
+    3: dict(W=2048, H=2048, frames=1000, content="mixed", layout="concat+scan",
+            name="configs[2]: 1000-frame 2048x2048 stream, mixed depths 0-8"),
+    4: dict(W=1921, H=1081, frames=2048, content="mixed", layout="slots",
+            name="configs[3]: 1921x1081 frames (edge tiles, constant-pad path)"),
+    5: dict(W=4096, H=3072, frames=10000, content="noise8", layout="stream",
+            name="configs[4]: 10000-frame 4096x3072 stream sharded by frame blocks"),
+}
 
 
-def cpu_baseline(images_host, n_avail, budget_s=12.0):
-    """Reference (oracle/_ref, kind 'reference') or oracle port timed on the host cores:
-    every thread round-trips its own frames; bounded to about `budget_s` seconds."""
+def kernels_fingerprint():
+    """Identity of the kernel sources a profile belongs to (profiles/hbm_traffic.json carries it)."""
+    h = hashlib.sha256()
+    for f in ("dbde_kernels.hip", "dbde_kernels.h", "dbde_bits.h"):
+        h.update(open(os.path.join(ROOT, "dbde-video-cpp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: become the launcher.  Nothing in this process has touched
+    the GPU (no torch.cuda call, no codec), and the ranks are CHILD processes -- never an exec."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baseline(make_frames, W, H, budget_s=12.0):
+    """Reference (oracle/_ref, kind 'reference') or oracle port on ALL host cores: every thread round-trips
+    its own frame; bounded to about `budget_s` seconds of wall time."""
     from oracle_ffi import Oracle, Reference
     impl, kind = (Reference(), "reference") if Reference.available() else (Oracle(), "port")
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16, n_avail))
-    # calibrate on one frame, one thread
-    t1 = impl.time_roundtrip(images_host[0:1], 1, W, H, 1)[0]
+    n_distinct = min(cores, 32)
+    images_host = make_frames(n_distinct)
+    t1 = impl.time_roundtrip(images_host[0:1], 1, W, H, 1)[0]   # calibrate on one frame, one thread
     reps = max(1, int(budget_s / max(t1, 1e-4)))
     results = [None] * cores
 
     def work(k):
-        results[k] = impl.time_roundtrip(images_host[k:k + 1], 1, W, H, reps)
+        j = k % n_distinct
+        results[k] = impl.time_roundtrip(images_host[j:j + 1], 1, W, H, reps)
 
     t0 = time.time()
     th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
@@ -63,9 +102,186 @@ def cpu_baseline(images_host, n_avail, budget_s=12.0):
     bad = sum(r[3] for r in results)
     frames = cores * reps
     return {"value": round(frames / wall, 2), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": f"{cores} threads x {reps} round trips of one 4096x3072 frame each ({frames} total, "
-                      f"{wall:.1f} s wall)",
+            "sample": f"{cores} threads (all host cores) x {reps} round trips of one {W}x{H} frame each "
+                      f"({frames} total, {wall:.1f} s wall)",
             "single_thread_frames_per_s": round(1.0 / t1, 2), "mismatched_pixels": int(bad)}
+
+
+class Bench:
+    def __init__(self, args, dv, torch, dist, world, rank, local):
+        self.args, self.dv, self.torch, self.dist = args, dv, torch, dist
+        self.world, self.rank, self.local = world, rank, local
+        self.dev = torch.device("cuda", local)
+        self.codec = dv.Codec(local)
+
+    def fence(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def case(self, W, H, B, content, layout, steps, warmup, check=True):
+        """Times `steps` encode+decode passes over B frames.  layout: 'slots' | 'concat' | 'concat+scan'
+        (decode from the offsets the device stream scanner finds, not from the encoder's)."""
+        torch, dv, codec, rank = self.torch, self.dv, self.codec, self.rank
+        imgs = codec.synth_frames(content, SEED, rank * B, B, W, H)
+        slot = ((dv.max_frame_bytes(W, H) + 255) // 256) * 256 if layout == "slots" else 0
+        buf, lead, cap = codec.alloc_stream(W, H, B, slot_stride=slot)
+        out = torch.empty_like(imgs)
+        offs = torch.empty(B, dtype=torch.int64, device=self.dev)
+        sizes = torch.empty(B, dtype=torch.int64, device=self.dev)
+        res = torch.empty((B, 4), dtype=torch.int64, device=self.dev)
+        scan = layout == "concat+scan"
+        packed_bytes = [0]
+        found = torch.empty(B, dtype=torch.int64, device=self.dev) if scan else None
+
+        def step():
+            codec.encode_frames(imgs, W, H, B, buf, lead, cap, first_index=rank * B, offsets=offs, nbytes=sizes,
+                                slot_stride=slot)
+            if scan:   # a reader's view: only the bytes and their total length are known
+                codec.index_stream_async(buf, lead, packed_bytes[0] or cap, W, H, B, found)
+                codec.decode_frames(buf, lead, packed_bytes[0] or cap, found, W, H, B, images=out, results=res)
+            else:
+                codec.decode_frames(buf, lead, cap, offs, W, H, B, images=out, results=res)
+
+        if scan:   # the stream length a reader would know (file size): one encode to learn it
+            codec.encode_frames(imgs, W, H, B, buf, lead, cap, first_index=rank * B, offsets=offs, nbytes=sizes)
+            codec.sync()
+            packed_bytes[0] = int((offs[-1] + sizes[-1]).item())
+        for _ in range(warmup):
+            step()
+        codec.sync()
+        if check:   # parity gate on the measured configuration
+            assert torch.equal(out, imgs), f"round trip mismatch ({W}x{H} {content} {layout})"
+            if scan:
+                assert torch.equal(found, offs), "stream scanner offsets differ from the encoder's"
+        packed = int(sizes.sum().item())
+
+        codec.timing(True)
+        codec.timing_read(reset=True)
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        tk = codec.timing_read(reset=True)
+        codec.timing(False)
+        codec.sync()
+        t_all = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        if self.dist is not None:
+            self.dist.all_reduce(t_all, op=self.dist.ReduceOp.MAX)
+        dt_max = float(t_all.item())
+
+        avg = lambda k: tk[k][0] / max(tk[k][1], 1)
+        enc_ms, idx_ms, dec_ms, scan_ms = avg("encode"), avg("decode_index"), avg("decode"), avg("scan")
+        raw = B * W * H
+        alg = raw + packed                              # encode reads raw, writes packed; decode the reverse
+        gbps = lambda ms: alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        r = {"W": W, "H": H, "frames_per_step_per_gpu": B, "content": content, "layout": layout,
+             "frames_per_s": round(self.world * B * steps / dt_max, 1),
+             "raw_pixel_GBps": round(self.world * B * steps / dt_max * W * H / 1e9, 1),
+             "ms_per_step": round(dt_max / steps * 1e3, 4), "steps": steps,
+             "packed_over_raw": round(packed / raw, 4), "algorithmic_bytes_per_launch": alg,
+             "encode": {"ms": round(enc_ms, 4), "GBps": round(gbps(enc_ms), 1), "frac": round(gbps(enc_ms) / HBM_PEAK_GBPS, 4)},
+             "decode": {"ms": round(dec_ms, 4), "GBps": round(gbps(dec_ms), 1), "frac": round(gbps(dec_ms) / HBM_PEAK_GBPS, 4),
+                        "index_ms": round(idx_ms, 4)},
+             "round_trip_frac": round(2 * alg / ((enc_ms + dec_ms + idx_ms + scan_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "identical": bool(check)}
+        if scan:
+            r["decode"]["scan_ms"] = round(scan_ms, 4)
+        r["_dt_max"], r["_packed"] = dt_max, packed
+        del imgs, buf, out
+        return r
+
+    def single_frame(self, W, H, content, reps=300):
+        """configs[1] literally: ONE frame per encode+decode call, device-resident, back to back."""
+        torch, dv, codec = self.torch, self.dv, self.codec
+        one = codec.synth_frames(content, SEED, 0, 1, W, H)
+        buf, lead, cap = codec.alloc_stream(W, H, 1)
+        out = torch.empty_like(one)
+        offs = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        sizes = torch.empty(1, dtype=torch.int64, device=self.dev)
+        res = torch.empty((1, 4), dtype=torch.int64, device=self.dev)
+
+        def step1():
+            codec.encode_frames(one, W, H, 1, buf, lead, cap, first_index=0, offsets=offs, nbytes=sizes)
+            codec.decode_frames(buf, lead, cap, offs, W, H, 1, images=out, results=res)
+        for _ in range(20):
+            step1()
+        codec.sync()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            step1()
+        codec.sync()
+        d1 = (time.perf_counter() - t1) / reps
+        alg = 2 * (W * H + int(sizes[0].item()))
+        return {"frames_per_step": 1, "us_per_round_trip": round(d1 * 1e6, 2), "frames_per_s": round(1.0 / d1, 1),
+                "GBps": round(alg / d1 / 1e9, 1), "identical": bool(torch.equal(out, one)),
+                "note": "one frame per encode+decode call, device-resident, back to back; the 25 MB working set "
+                        "stays in the 256 MiB Infinity Cache, so this is a latency figure, not an HBM one"}
+
+    def stream(self, W, H, n_total, batch, content, gather_mode):
+        """configs[4]: every rank walks its contiguous block of the n_total frames through the streaming
+        driver; returns kernels-only and with-gather columns."""
+        from dbde_video_cpp_amd import distributed as dd
+        from dbde_video_cpp_amd.streaming import RoundTripStream
+        torch, dv = self.torch, self.dv
+        lo, hi = dd.shard_frames(n_total, self.rank, self.world)
+        side = torch.cuda.Stream(self.dev)
+        src_codec = dv.Codec(self.local, stream=side)            # frame source: its own stream
+
+        def source(first, n, out):
+            src_codec.synth_frames(content, SEED, first, n, W, H, out=out)
+
+        cols = {}
+        for name, g in (("kernels_only", None), ("with_gather", gather_mode)):
+            if name == "with_gather" and g is None:
+                continue
+            rts = RoundTripStream(self.codec, W, H, batch, source=source, source_stream=side, gather=g)
+            self.fence()
+            r = rts.run(lo, hi - lo, self.world, self.rank)
+            t = torch.tensor([r["seconds"]], dtype=torch.float64, device=self.dev)
+            if self.dist is not None:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            sec = float(t.item())
+            cols[name] = {"frames_per_s": round(n_total / sec, 1), "seconds": round(sec, 4),
+                          "batches_per_rank": r["batches"]}
+            if g:
+                cols[name]["gathered_bytes"] = r["gathered_bytes"]
+                cols[name]["GBps_into_root"] = round((r["gathered_bytes"] - r["packed_bytes"]) / sec / 1e9, 1)
+            del rts
+        src_codec.close()
+        return cols, (lo, hi)
+
+
+def dry_run(args, world, rank, dist):
+    """Launch-contract rehearsal without a GPU (tests/test_bench_contract.py): N ranks, sharding, barrier,
+    max-over-ranks and the gloo gather of a fabricated stream.  Measures nothing and says so."""
+    import torch
+    from dbde_video_cpp_amd import distributed as dd
+    lo, hi = dd.shard_frames(args.frames * world, rank, world)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    gathered = None
+    if dist is not None:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seg = torch.full((100 + 7 * rank,), rank, dtype=torch.uint8)
+        stream, sizes = dd.gather_stream(seg, seg.numel(), dst=0)
+        gathered = sum(sizes)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "value": 0.0,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+                          "data": "none (dry run: launch contract only, no GPU work, not a measurement)",
+                          "dry_run": True, "frames_of_rank0": [lo, hi], "gathered_bytes": gathered,
+                          "config": {"workload": "dry run"}}), flush=True)
 
 
 def main():
@@ -73,184 +289,142 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per step per GPU")
-    ap.add_argument("--content", default="noise8", choices=["noise8", "mixed", "smooth", "flat"])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[config-1] as the headline")
+    ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default: the config's)")
+    ap.add_argument("--content", default=None, choices=["noise8", "mixed", "smooth", "flat"])
+    ap.add_argument("--concat", action="store_true", help="one concatenated stream instead of one slot per frame")
+    ap.add_argument("--batch", type=int, default=250, help="frames per batch of the streaming driver (config 5)")
+    ap.add_argument("--only", action="store_true", help="headline leg only (profiling runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--no-single", action="store_true", help="skip the one-frame-per-call leg (profiling runs)")
-    ap.add_argument("--concat", action="store_true", help="one concatenated stream instead of one slot per frame")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-frame-per-call leg")
     ap.add_argument("--no-check", action="store_true", help="(experiments) skip the round-trip parity gate")
+    ap.add_argument("--dry-run", action="store_true", help="launch contract only: no GPU, no codec (CPU tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+
+    import torch
     dist = None
+    # rehearsal on a one-GPU box: DBDE_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo (exercises the
+    # launch contract, sharding, barrier, max-over-ranks and the staged gather pipeline; not a measurement)
+    rehearsal = os.environ.get("DBDE_BENCH_REHEARSAL") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # rehearsal on a one-GPU box: DBDE_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo
-        # (exercises the launch contract, sharding, barrier and max-over-ranks; not a measurement)
-        rehearsal = os.environ.get("DBDE_BENCH_REHEARSAL") == "1"
-        if rehearsal:
-            local = 0
-        torch.cuda.set_device(local)
-        if rehearsal:
+        if args.dry_run:
             dist.init_process_group("gloo")
-            args.no_gather = True
+        elif rehearsal:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
         else:
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
+        assert dist.get_world_size() == args.gpus
+    if args.dry_run:
+        args.frames = args.frames or 16
+        dry_run(args, world, rank, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if world == 1:
         torch.cuda.set_device(0)
         local = 0
-    dev = torch.device("cuda", local)
-    codec = dv.Codec(local)
-    B = args.frames
-    T = (W // 8) * (H // 8)
 
-    # ---- inputs resident in HBM before the timed region ------------------------------------
-    imgs = codec.synth_frames(args.content, SEED, rank * B, B, W, H)
-    slot = 0 if args.concat else ((dv.max_frame_bytes(W, H) + 255) // 256) * 256
-    buf, lead, cap = codec.alloc_stream(W, H, B, slot_stride=slot)
-    out = torch.empty_like(imgs)
-    offs = torch.empty(B, dtype=torch.int64, device=dev)
-    sizes = torch.empty(B, dtype=torch.int64, device=dev)
-    res = torch.empty((B, 4), dtype=torch.int64, device=dev)
-    stream_cap = cap
+    import dbde_video_cpp_amd as dv
+    b = Bench(args, dv, torch, dist, world, rank, local)
+    cfg = dict(CONFIGS[args.config])
+    W, H = cfg["W"], cfg["H"]
+    content = args.content or cfg["content"]
+    gather_mode = None if (dist is None or args.no_gather) else ("host" if rehearsal else "nccl")
 
-    def step():
-        codec.encode_frames(imgs, W, H, B, buf, lead, cap, first_index=rank * B, offsets=offs, nbytes=sizes, slot_stride=slot)
-        codec.decode_frames(buf, lead, stream_cap, offs, W, H, B, images=out, results=res)
+    line = {"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "unit": "frames/s",
+            "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+    if rehearsal:
+        line["rehearsal"] = "all ranks on cuda:0 over gloo: launch-contract check, NOT a scaling measurement"
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    codec.sync()
-    # parity gate on the measured configuration: round trip identical, sizes consistent
-    assert args.no_check or torch.equal(out, imgs), "round trip mismatch"
-    s_h = sizes.cpu().numpy()
-    packed_bytes = int(s_h.sum())
-
-    codec.timing(True)
-    codec.timing_read(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    tk = codec.timing_read(reset=True)
-    codec.timing(False)
-    codec.sync()
-
-    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    dt_max = float(t_all.item())
-    frames_total = world * B * args.steps
-    fps = frames_total / dt_max
-
-    # ---- roofline of the kernels (HIP events on the codec's stream, inside the timed region) --
-    raw = B * W * H
-    enc_ms = tk["encode"][0] / max(tk["encode"][1], 1)
-    dec_ms = tk["decode"][0] / max(tk["decode"][1], 1)
-    idx_ms = tk["decode_index"][0] / max(tk["decode_index"][1], 1)
-    alg = raw + packed_bytes                      # encode reads raw, writes packed; decode the reverse
-    enc_gbps = alg / (enc_ms * 1e-3) / 1e9
-    dec_gbps = alg / (dec_ms * 1e-3) / 1e9
-    fw_min = int(os.environ.get("DBDE_HIP_FRAMEWISE_MIN", "0"))
-    enc_name = "dbde::encode_framewise_kernel" if (slot and fw_min and B >= fw_min) else "dbde::encode_kernel"
-    dom = (enc_name, enc_ms, enc_gbps) if enc_ms >= dec_ms else ("dbde::decode_kernel", dec_ms, dec_gbps)
-    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(dom[2], 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(dom[2] / HBM_PEAK_GBPS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": alg, "launch_ms": round(dom[1], 4),
-                "encode": {"ms": round(enc_ms, 4), "GBps": round(enc_gbps, 1), "frac": round(enc_gbps / HBM_PEAK_GBPS, 4)},
-                "decode": {"ms": round(dec_ms, 4), "GBps": round(dec_gbps, 1), "frac": round(dec_gbps / HBM_PEAK_GBPS, 4),
-                           "index_ms": round(idx_ms, 4)},
-                "round_trip_frac": round(2 * alg / ((enc_ms + dec_ms + idx_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file):
-        try:
-            t = json.load(open(traffic_file)).get(args.content, {})
-            # per-launch HBM bytes from the rocprofv3 PMC passes (profiles/*_summary.txt), same batch
-            roofline["traffic"] = t.get(dom[0]) if t.get("frames_per_launch") == B else None
-        except Exception:
-            pass
-
-    # ---- RCCL gather of the compressed stream to rank 0 (not on the round-trip path) ----------
-    gather = None
-    if dist is not None and not args.no_gather:
-        from dbde_video_cpp_amd import distributed as dd
-        if slot:   # the gathered stream is the concatenated form: re-encode this rank's block that way once
-            codec.encode_frames(imgs, W, H, B, buf, lead, cap, first_index=rank * B, offsets=offs, nbytes=sizes)
-            codec.sync()
-        seg = buf[lead:lead + packed_bytes]
-        recv = None
-        if rank == 0:
-            recv = torch.empty(world * (cap + 64), dtype=torch.uint8, device=dev)
-        dd.gather_stream(seg, packed_bytes, dst=0, out=recv)      # warm-up (connection setup)
-        fence()
-        tg0 = time.perf_counter()
-        reps = 2
-        for _ in range(reps):
-            stream, allsz = dd.gather_stream(seg, packed_bytes, dst=0, out=recv)
-        fence()
-        tg = (time.perf_counter() - tg0) / reps
-        del recv, stream
-        gather = {"ms": round(tg * 1e3, 3), "bytes": sum(allsz),
-                  "GBps_into_root": round((sum(allsz) - allsz[0]) / tg / 1e9, 1),
-                  "frames_per_s_if_serialised": round(world * B / (dt_max / args.steps + tg), 1),
-                  "note": "variable-length gather of the compressed stream to rank 0 over RCCL; measured "
-                          "separately, not inside the round-trip steps"}
-
-    # ---- configs[1] literally: ONE frame per call (launch-bound; reported beside the batched value) ----
-    single = None
-    if rank == 0 and world == 1 and not args.no_single:
-        one, ob, oo = imgs[:1], buf, out[:1]
-        def step1():
-            codec.encode_frames(one, W, H, 1, ob, lead, cap, first_index=0, offsets=offs[:1], nbytes=sizes[:1], slot_stride=slot)
-            codec.decode_frames(ob, lead, stream_cap, offs[:1], W, H, 1, images=oo, results=res[:1])
-        for _ in range(20):
-            step1()
-        codec.sync()
-        reps1 = 300
-        t1 = time.perf_counter()
-        for _ in range(reps1):
-            step1()
-        codec.sync()
-        d1 = (time.perf_counter() - t1) / reps1
-        single = {"frames_per_step": 1, "us_per_round_trip": round(d1 * 1e6, 2), "frames_per_s": round(1.0 / d1, 1),
-                  "identical": bool(torch.equal(oo, one)),
-                  "note": "one 4096x3072 frame per encode+decode call, device-resident, back to back: bounded by "
-                          "kernel launch and start-up latency, not by HBM"}
+    if args.config == 5:
+        # ---- the 10,000-frame stream: strong scaling over frame blocks, streaming driver -------------------
+        n_total = args.frames or cfg["frames"]
+        cols, (lo, hi) = b.stream(W, H, n_total, args.batch, content, gather_mode)
+        head = cols.get("with_gather", cols["kernels_only"])
+        line.update({"value": head["frames_per_s"], "raw_pixel_GBps": round(head["frames_per_s"] * W * H / 1e9, 1),
+                     "ms_per_step": round(head["seconds"] / max(head["batches_per_rank"], 1) * 1e3, 4),
+                     "steps": head["batches_per_rank"], "warmup": 0, "scaling": "strong",
+                     "config": {"workload": f"BASELINE {cfg['name']}: {n_total} frames {W}x{H} {content}, rank blocks of "
+                                            f"{hi - lo}, batches of {args.batch} through the streaming driver (frames "
+                                            "produced on the fly on a side stream, two input and two stream slots)",
+                                "content": content, "batch": args.batch, "parallelism": f"frame blocks x{world}"},
+                     "stream": cols,
+                     "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                                  "traffic": None, "note": "streaming run: see the default run for the kernels' roofline"}})
+    else:
+        B = args.frames or cfg["frames"]
+        layout = "concat" if args.concat else cfg["layout"]
+        r = b.case(W, H, B, content, layout, args.steps, args.warmup, check=not args.no_check)
+        enc, dec = r["encode"], r["decode"]
+        dom = ("dbde::encode_kernel", enc) if enc["ms"] >= dec["ms"] else ("dbde::decode_kernel", dec)
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": dom[1]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(dom[1]["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
+                    "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "launch_ms": dom[1]["ms"],
+                    "encode": enc, "decode": dec, "round_trip_frac": r["round_trip_frac"]}
+        # HBM bytes per launch from the rocprofv3 PMC passes (profiles/*_summary.txt): replayed from the
+        # committed record ONLY when it was taken on these kernel sources and this workload, else null
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf))
+                t = rec.get(f"cfg{args.config}_{content}", {})
+                if rec.get("kernels_sha") == kernels_fingerprint() and t.get("frames_per_launch") == B and t.get(dom[0]):
+                    roofline["traffic"] = t[dom[0]]
+                    roofline["traffic_source"] = f"replayed: rocprofv3 --pmc passes of {rec.get('tag')} on these kernel sources"
+            except Exception:
+                pass
+        line.update({"value": r["frames_per_s"], "raw_pixel_GBps": r["raw_pixel_GBps"], "ms_per_step": r["ms_per_step"],
+                     "scaling": "weak",
+                     "config": {"workload": f"BASELINE {cfg['name']}, {content}, {B} distinct frames per step per GPU, "
+                                            f"device-resident in and out, layout {layout}",
+                                "frames_per_step_per_gpu": B, "content": content, "layout": layout, "W": W, "H": H,
+                                "packed_over_raw": r["packed_over_raw"], "parallelism": f"frames sharded x{world}"},
+                     "roofline": roofline})
+        strip = lambda d: {k: v for k, v in d.items() if not k.startswith("_")}
+        if not args.only:
+            sub_steps = max(3, args.steps // 2)
+            # ---- the bit-packing path and low-entropy content at the headline shape ----------------------------
+            line["contents"] = {}
+            for c in ("mixed", "smooth"):
+                if c != content:
+                    line["contents"][c] = strip(b.case(W, H, B, c, layout, sub_steps, 2))
+            # ---- the other single-GPU configs, same method -----------------------------------------------------
+            line["configs"] = {}
+            for k in (2, 3, 4):
+                if k != args.config and world == 1:
+                    c = CONFIGS[k]
+                    line["configs"][str(k)] = strip(b.case(c["W"], c["H"], c["frames"], c["content"], c["layout"], sub_steps, 2))
+                    line["configs"][str(k)]["workload"] = c["name"]
+        # ---- gather pipeline (N > 1): batch k's compressed bytes travel while batch k+1 is encoded -------------
+        if gather_mode and not args.only:
+            cols, _ = b.stream(W, H, world * 4 * min(B, 256), min(B, 256), content, gather_mode)
+            line["gather"] = {"kernels_only": cols["kernels_only"], "with_gather": cols["with_gather"],
+                              "note": "streaming driver, 4 batches per rank: variable-length gather of each batch's "
+                                      "compressed bytes to rank 0 (RCCL send/recv) overlapped with the next batch's "
+                                      "encode+decode; root ingress over xGMI bounds the second column"}
+        if rank == 0 and world == 1 and not args.no_single and not args.only:
+            line["single_frame"] = b.single_frame(4096, 3072, "noise8")
+            line["single_frame"]["mixed_us_per_round_trip"] = b.single_frame(4096, 3072, "mixed")["us_per_round_trip"]
 
     if rank == 0:
-        line = {
-            "metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip",
-            "value": round(fps, 1), "unit": "frames/s",
-            "raw_pixel_GBps": round(fps * W * H / 1e9, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] shape: 4096x3072 U8 frames, {args.content}, "
-                                   f"{B} distinct frames per step per GPU, device-resident in and out, "
-                                   + ("one concatenated stream" if args.concat else "one slot per frame"),
-                       "frames_per_step_per_gpu": B, "content": args.content,
-                       "layout": "concat" if args.concat else "slots",
-                       "packed_over_raw": round(packed_bytes / raw, 4), "parallelism": f"frames sharded x{world}"},
-            "roofline": roofline,
-        }
-        if single:
-            line["single_frame"] = single
-        if gather:
-            line["gather"] = gather
-        if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(imgs[:16].cpu().numpy(), 16)
+        if not args.no_cpu and world == 1 and not args.only:
+            mk = lambda n: b.codec.synth_frames("noise8", SEED, 0, n, 4096, 3072).cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(mk, 4096, 3072)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -35,7 +35,8 @@ MODES = {"noise8": 0, "mixed": 1, "flat": 2, "smooth": 3}
 C_ABI_SYMBOLS = [
     "dbde_hip_create", "dbde_hip_destroy", "dbde_hip_sync", "dbde_hip_last_error", "dbde_hip_device_arch",
     "dbde_hip_max_frame_bytes", "dbde_hip_image_bytes",
-    "dbde_hip_encode_frames", "dbde_hip_decode_frames", "dbde_hip_index_stream", "dbde_hip_synth_frames",
+    "dbde_hip_encode_frames", "dbde_hip_decode_frames", "dbde_hip_index_stream", "dbde_hip_index_stream_async",
+    "dbde_hip_synth_frames",
     "dbde_hip_pack_8x8", "dbde_hip_pack_8x8_partial", "dbde_hip_pack_image", "dbde_hip_pack_frame",
     "dbde_hip_unpack_8x8", "dbde_hip_unpack_8x8_partial", "dbde_hip_unpack_image", "dbde_hip_unpack_frame",
     "dbde_hip_pack_frame_header", "dbde_hip_pack_video_header",
@@ -102,6 +103,8 @@ def lib():
     L.dbde_hip_decode_frames.argtypes = [vp, vp, sz, vp, i, i, i, vp, vp]
     L.dbde_hip_index_stream.restype = i
     L.dbde_hip_index_stream.argtypes = [vp, vp, sz, i, i, i, vp, C.POINTER(i)]
+    L.dbde_hip_index_stream_async.restype = i
+    L.dbde_hip_index_stream_async.argtypes = [vp, vp, sz, i, i, i, vp, vp]
     L.dbde_hip_synth_frames.restype = i
     L.dbde_hip_synth_frames.argtypes = [vp, i, u64, u64, i, i, i, vp]
     L.dbde_hip_pack_8x8.restype = C.c_uint32
@@ -286,6 +289,16 @@ class Codec:
         self._check(rc, "dbde_hip_index_stream")
         return offsets[:n.value], n.value
 
+    def index_stream_async(self, stream, stream_offset, stream_bytes, W, H, max_frames, offsets, count=None):
+        """Enqueues the frame-to-frame walk; offsets (int64 device tensor, >= max_frames) and the device
+        word `count` (int32 tensor, 1 element) are valid once the stream reaches this point."""
+        if count is None:
+            count = torch.empty(1, dtype=torch.int32, device=self.device)
+        rc = self.L.dbde_hip_index_stream_async(self.h, stream.data_ptr() + stream_offset, stream_bytes, W, H,
+                                                max_frames, offsets.data_ptr(), count.data_ptr())
+        self._check(rc, "dbde_hip_index_stream_async")
+        return offsets, count
+
     @staticmethod
     def parse_results(results):
         """results tensor (n,4) int64 -> list of (u64s, index, elapsed_ns, consumed)."""
@@ -355,10 +368,10 @@ class Codec:
         self._check(self.L.dbde_hip_timing_enable(self.h, 1 if on else 0), "dbde_hip_timing_enable")
 
     def timing_read(self, reset=True):
-        ms = (C.c_double * 3)()
-        n = (C.c_uint64 * 3)()
+        ms = (C.c_double * 4)()
+        n = (C.c_uint64 * 4)()
         self._check(self.L.dbde_hip_timing_read(self.h, ms, n, 1 if reset else 0), "dbde_hip_timing_read")
-        return {"encode": (ms[0], n[0]), "decode_index": (ms[1], n[1]), "decode": (ms[2], n[2])}
+        return {"encode": (ms[0], n[0]), "decode_index": (ms[1], n[1]), "decode": (ms[2], n[2]), "scan": (ms[3], n[3])}
 
 
 class FileWriter:

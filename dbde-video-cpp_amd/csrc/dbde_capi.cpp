@@ -39,7 +39,7 @@ struct dbde_hip_ctx {
     std::string arch;
 
     // look-back workspace: [ctrl: 4 x u32][state: n_chunks x u64], zeroed before every encode
-    void *lb = nullptr;
+    uint8_t *lb = nullptr;
     size_t lb_bytes = 0;
     // decode workspace
     uint32_t *chunk_off = nullptr;
@@ -62,8 +62,8 @@ struct dbde_hip_ctx {
     uint64_t *diag = nullptr;        // [16] phase cycle sums of diagnostic launches
     bool timing = false;
     std::vector<TimedSpan> spans;
-    double acc_ms[3] = {0, 0, 0};
-    uint64_t acc_n[3] = {0, 0, 0};
+    double acc_ms[4] = {0, 0, 0, 0};     // encode, decode index, decode, stream scan
+    uint64_t acc_n[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -256,22 +256,12 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
 
     const uint32_t n_chunks = (uint32_t)n_chunks64;
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
-    {
-        size_t have = ctx->lb_bytes;
-        uint8_t *p = reinterpret_cast<uint8_t *>(ctx->lb);
-        int rc = grow(ctx, p, have, lb_need, 1, getenv("DBDE_HIP_LB_CACHED") == nullptr);
+    {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
+        int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);
         if (rc) return rc;
-        ctx->lb = p;
-        ctx->lb_bytes = have;
     }
-    const size_t zero_bytes = lb_need;
-    // Frame-wise kernel (opt-in, $DBDE_HIP_FRAMEWISE_MIN = smallest batch that uses it): slot layout,
-    // a workgroup owns whole frames.  Measured slower than the scanning encoder (locality), kept for A/B.
-    uint32_t fw_min = 0;   // off by default: the scanning encoder is faster at every batch size
-    if (const char *e = getenv("DBDE_HIP_FRAMEWISE_MIN")) fw_min = (uint32_t)strtoul(e, nullptr, 0);
-    const bool framewise = slot_stride != 0 && fw_min != 0 && (uint32_t)n_frames >= fw_min;
     span_begin(ctx, 0);
-    if (!framewise) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, zero_bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
 
     EncParams p;
     p.images = d_images;
@@ -282,7 +272,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.elapsed_ns = d_elapsed_ns;
     p.first_index = first_index;
     p.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
-    p.state = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(ctx->lb) + 16);
+    p.state = reinterpret_cast<unsigned long long *>(ctx->lb + 16);
     p.sticky = ctx->sticky;
     p.slot_stride = slot_stride;
     p.frame_pixels = g.pixels;
@@ -298,15 +288,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     const bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);
-    if (framewise) {
-        int fw_waves = 8;
-        if (const char *e = getenv("DBDE_HIP_FRAMEWISE_WAVES")) fw_waves = atoi(e) == 4 ? 4 : 8;
-        const uint32_t ct = (uint32_t)fw_waves * 128u;
-        p.chunks_per_frame = (g.T + ct - 1) / ct;
-        p.n_chunks = (uint32_t)n_frames * p.chunks_per_frame;
-        HIP_TRY(ctx, launch_encode_framewise(p, fw_waves, fast_in, aligned_out, ctx->stream));
-    }
-    else HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
+    HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;
 }
@@ -321,9 +303,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
         return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
-    uint32_t dec_ct = 512;   // tiles per decode workgroup ($DBDE_HIP_DEC_CHUNK = 256 for smaller workgroups)
-    if (const char *e = getenv("DBDE_HIP_DEC_CHUNK")) dec_ct = atoi(e) == 256 ? 256u : (atoi(e) == 1024 ? 1024u : 512u);
-    const uint32_t dcpf = (g.T + dec_ct - 1) / dec_ct;
+    const uint32_t dcpf = g.cpf;   // chunks of kChunkTiles tiles, one decode workgroup each
     if (dcpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
     const uint64_t n_chunks64 = (uint64_t)n_frames * dcpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
@@ -342,13 +322,13 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     ip.results = d_results;
     ip.T = g.T;
     ip.chunks_per_frame = dcpf;
-    ip.chunk_shift = dec_ct == 256u ? 8u : (dec_ct == 1024u ? 10u : 9u);
+    ip.chunk_shift = kChunkShift;
     // Few frames: cut each frame into pieces so that the index pass fills the device too
     // (>= 4 chunks per piece, about 1024 workgroups in all); from 256 frames on, one workgroup per frame.
     ip.split = 1;
     ip.frame_ctr = nullptr;
     ip.frame_flag = nullptr;
-    if (n_frames < 256 && dcpf >= 8u && !getenv("DBDE_HIP_IDX_NOSPLIT")) {
+    if (n_frames < 256 && dcpf >= 8u) {
         uint32_t sp = 1024u / (uint32_t)n_frames;
         const uint32_t most = (dcpf + 3u) / 4u;
         if (sp > most) sp = most;
@@ -370,6 +350,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     DecParams p;
     p.stream = d_stream;
     p.frame_offsets = d_frame_offsets;
+    p.stream_bytes = stream_bytes;
     p.images = d_images;
     p.chunk_off = ctx->chunk_off;
     p.frame_ok = ctx->frame_ok;
@@ -381,7 +362,6 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.T = g.T;
     p.chunks_per_frame = dcpf;
     p.n_chunks = (uint32_t)n_chunks64;
-    p.chunk_tiles = dec_ct;
     const bool fast_img = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
     span_begin(ctx, 2);
     HIP_TRY(ctx, launch_decode(p, fast_img, ctx->stream));
@@ -389,15 +369,25 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     return DBDE_HIP_OK;
 }
 
-int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W, int H,
-                          int max_frames, uint64_t *d_frame_offsets, int *n_found) {
+int dbde_hip_index_stream_async(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W, int H,
+                                int max_frames, uint64_t *d_frame_offsets, uint32_t *d_n_found) {
     if (!ctx) return DBDE_HIP_ERR_ARG;
     Geometry g;
-    if (!d_stream || !d_frame_offsets || !n_found || max_frames < 0 || !geometry(W, H, g))
+    if (!d_stream || !d_frame_offsets || !d_n_found || max_frames < 0 || !geometry(W, H, g))
         return fail(ctx, DBDE_HIP_ERR_ARG, "index_stream: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    span_begin(ctx, 3);
+    HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, ctx->stream));
+    span_end(ctx);
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W, int H,
+                          int max_frames, uint64_t *d_frame_offsets, int *n_found) {
+    if (!ctx || !n_found) return DBDE_HIP_ERR_ARG;
     uint32_t *d_count = reinterpret_cast<uint32_t *>(ctx->scratch64);
-    HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_count, ctx->stream));
+    int rc = dbde_hip_index_stream_async(ctx, d_stream, stream_bytes, W, H, max_frames, d_frame_offsets, d_count);
+    if (rc) return rc;
     uint32_t cnt = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -474,15 +464,12 @@ uint32_t dbde_hip_pack_8x8(dbde_hip_ctx *ctx, const uint8_t *image, int stride, 
 // Runs index + decode for one frame_data already resident at ctx->st_pack + 20 (a dummy
 // frame header precedes it).  Returns bytes of frame data consumed (0 = rejected) and leaves
 // the image in ctx->st_img.
-static size_t decode_one_staged(dbde_hip_ctx *ctx, size_t staged_bytes, int W, int H, bool prefill,
-                                const uint8_t *image_in) {
+static size_t decode_one_staged(dbde_hip_ctx *ctx, size_t staged_bytes, int W, int H) {
     Geometry g;
     if (!geometry(W, H, g)) return 0;
     uint64_t *d_off = ctx->scratch64 + 2;
     const uint64_t zero = 0;
     if (hipMemcpyAsync(d_off, &zero, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
-    (void)prefill;
-    (void)image_in;
     dbde_hip_frame_result *d_res = reinterpret_cast<dbde_hip_frame_result *>(ctx->st_pack + ((staged_bytes + 63) & ~(size_t)63));
     if (dbde_hip_decode_frames(ctx, ctx->st_pack, staged_bytes, d_off, W, H, 1, ctx->st_img, d_res) != DBDE_HIP_OK) return 0;
     dbde_hip_frame_result res;
@@ -507,7 +494,7 @@ size_t dbde_hip_unpack_image(dbde_hip_ctx *ctx, const uint8_t *packed, int W, in
     dbde_hip_pack_frame_header(&fh, hdr);
     if (hipMemcpyAsync(ctx->st_pack, hdr, 20, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
     if (hipMemcpyAsync(ctx->st_pack + 20, packed, body, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
-    const size_t used = decode_one_staged(ctx, 20 + body, W, H, false, nullptr);
+    const size_t used = decode_one_staged(ctx, 20 + body, W, H);
     if (!used) return 0;
     if (hipMemcpy(image, ctx->st_img, (size_t)g.pixels, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return used;
@@ -600,7 +587,7 @@ int dbde_hip_timing_enable(dbde_hip_ctx *ctx, int on) {
     return DBDE_HIP_OK;
 }
 
-int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[3], uint64_t launches[3], int reset) {
+int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[4], uint64_t launches[4], int reset) {
     if (!ctx) return DBDE_HIP_ERR_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &s : ctx->spans) {
@@ -613,7 +600,7 @@ int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[3], uint64_t launches[3], 
         (void)hipEventDestroy(s.b);
     }
     ctx->spans.clear();
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         if (ms) ms[k] = ctx->acc_ms[k];
         if (launches) launches[k] = ctx->acc_n[k];
         if (reset) { ctx->acc_ms[k] = 0; ctx->acc_n[k] = 0; }

@@ -7,9 +7,12 @@ namespace dbde {
 
 // A chunk is the unit of one 256-thread workgroup: 512 consecutive tiles in stream order
 // (row-major over the frame's tiles), two tiles per lane.
-constexpr int kBlockThreads = 256;
-constexpr uint32_t kChunkTiles = 512;
-constexpr uint32_t kMaxChunkWords = kChunkTiles * 8;   // U64 words of payload per chunk, worst case
+#ifndef DBDE_DEC_CT
+#define DBDE_DEC_CT 512   // compile-time only (A/B builds in profiles/variants.sh); the shipped library is 512
+#endif
+constexpr uint32_t kChunkTiles = DBDE_DEC_CT;
+constexpr uint32_t kChunkShift = kChunkTiles == 256 ? 8 : (kChunkTiles == 1024 ? 10 : 9);
+static_assert((1u << kChunkShift) == kChunkTiles, "decode chunk must be 256, 512 or 1024 tiles");
 // The encoder walks larger chunks (fewer ticket draws): one 512-thread workgroup per 1024 tiles.
 constexpr uint32_t kEncChunkTiles = 1024;
 
@@ -44,6 +47,7 @@ struct EncParams {
 struct DecParams {
     const uint8_t *stream;
     const uint64_t *frame_offsets;  // [n_frames] byte offset of each frame header
+    uint64_t stream_bytes;          // readable extent of stream: nothing beyond it is touched
     uint8_t *images;
     const uint32_t *chunk_off;      // [n_frames][chunks_per_frame + 1] payload word offset of each chunk inside its frame (+ total)
     const uint32_t *frame_ok;       // [n_frames] 1 = frame data validated
@@ -51,7 +55,6 @@ struct DecParams {
     int W, H;
     uint32_t w, h, T;
     uint32_t chunks_per_frame, n_chunks;
-    uint32_t chunk_tiles;           // 512 (default), 256 or 1024: tiles per workgroup
 };
 
 struct IdxParams {
@@ -77,8 +80,6 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 };
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
-// Slot layout with at least as many frames as resident workgroups: no inter-workgroup state at all.
-hipError_t launch_encode_framewise(const EncParams &p, int waves, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s);

@@ -19,9 +19,6 @@
 
 #include "dbde_bits.h"
 
-#ifndef DBDE_PACK2
-#define DBDE_PACK2 1   // straight-line two-tile pack in the frame-wise encoder
-#endif
 #ifndef DBDE_NT
 #define DBDE_NT 1   // non-temporal hint on the streamed-once traffic (pixels, payload, decoded images)
 #endif
@@ -331,13 +328,13 @@ struct ChunkRef {
     bool valid, hasA, hasB;
 };
 
-__device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, int tidw, uint32_t chunk_tiles = kEncChunkTiles) {
+__device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, int tidw) {
     ChunkRef k;
     k.c = c;
     k.valid = c < p.n_chunks;
     k.f = k.valid ? c / p.chunks_per_frame : 0u;
     k.cf = k.valid ? c - k.f * p.chunks_per_frame : 0u;
-    k.t0 = k.cf * chunk_tiles + 2u * (uint32_t)tidw;
+    k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
     k.hasA = k.valid && k.t0 < p.T;
     k.hasB = k.valid && k.t0 + 1u < p.T;
     return k;
@@ -455,37 +452,6 @@ __device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, 
         const uint64_t row = pack_row_dot(v[2 * r] - m4, v[2 * r + 1] - m4, d, w_lo, w_hi, is8);
         uint64_t word;
         if (fn.push(row, 8u * d, word)) { pay[swzq8(q)] = word; q++; }
-    }
-}
-
-// Both tiles of the lane advance together, straight-line (no exec-mask branches): a row that does
-// not complete a word writes to the lane's trash word instead, so the scheduler can interleave the
-// two dependency chains.
-__device__ __forceinline__ void pack_two_tiles(const uint32_t (&va)[16], uint32_t mnA, uint32_t dA, uint32_t qA,
-                                               const uint32_t (&vb)[16], uint32_t mnB, uint32_t dB, uint32_t qB,
-                                               uint64_t *pay, uint32_t trash) {
-    const uint32_t mA = mnA * 0x01010101u, mB = mnB * 0x01010101u;
-    const uint32_t wA = 1u | ((1u << dA) << 8), wB = 1u | ((1u << dB) << 8);
-    const bool a8 = dA >= 8u, b8 = dB >= 8u;
-    const uint32_t nbA = 8u * dA, nbB = 8u * dB;
-    uint64_t accA = 0, accB = 0;
-    uint32_t fillA = 0, fillB = 0;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint64_t rowA = pack_row_dot(va[2 * r] - mA, va[2 * r + 1] - mA, dA, wA, wA << 16, a8);
-        const uint64_t rowB = pack_row_dot(vb[2 * r] - mB, vb[2 * r + 1] - mB, dB, wB, wB << 16, b8);
-        const uint64_t wordA = accA | (rowA << fillA), wordB = accB | (rowB << fillB);
-        const uint32_t nfA = fillA + nbA, nfB = fillB + nbB;
-        const bool emitA = nfA >= 64u, emitB = nfB >= 64u;
-        const uint64_t spillA = (rowA >> 1) >> (63u - fillA), spillB = (rowB >> 1) >> (63u - fillB);
-        accA = emitA ? spillA : wordA;
-        accB = emitB ? spillB : wordB;
-        fillA = nfA & 63u;
-        fillB = nfB & 63u;
-        pay[emitA ? swzq8(qA) : trash] = wordA;
-        pay[emitB ? swzq8(qB) : trash] = wordB;
-        qA += emitA ? 1u : 0u;
-        qB += emitB ? 1u : 0u;
     }
 }
 
@@ -612,10 +578,15 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     // One pipeline step.  `ca/cb` hold the pixels of cur (loaded one step ago), `na/nb` receive
     // those of nxt; the caller alternates the two register sets instead of copying them, so the
     // loads issued here are not waited for until the NEXT step's statistics.
-    // Returns 0 = finished, 1 = continue, 2 = failed (look-back time-out).
+    // A step never leaves early: once the workgroup has run out of chunks (or a look-back timed out) the
+    // remaining step of the pair runs empty -- dummy loads, no record, no stores -- so that the loop below
+    // has ONE exit, behind step 1.  With an exit between the two steps the compiler's wait-count analysis
+    // sees an edge from the end of step 0 back to the loop header, believes the registers step 0 has just
+    // requested may still be in flight when step 0 starts again, and protects their reuse as address
+    // temporaries with vmcnt(0): every step then waited for ALL of its previous stores to be acknowledged
+    // before it issued its prefetch (tests/test_kernel_listing.py pins the absence of that wait).
     auto step = [&](const uint32_t par, uint32_t (&ca)[16], uint32_t (&cb)[16], uint32_t (&na)[16],
-                    uint32_t (&nb)[16]) __attribute__((always_inline)) -> int {
-        if (!cur.valid && !prev.valid) return 0;
+                    uint32_t (&nb)[16]) __attribute__((always_inline)) -> void {
 
         // ---- 1. mailbox of prev and the next ticket, before this iteration's loads --------------
         if (tid == 0) {
@@ -660,9 +631,18 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
             }
         }
         __syncthreads();   // ---- 4. the one workgroup barrier ----
-        const uint32_t inf = sh.lb[par][0], glob = sh.lb[par][1], lb_ok = sh.lb[par][2];
+        const uint32_t inf = sh.lb[par][0], glob = sh.lb[par][1];
+        // wave-uniform on purpose: a divergent exit test makes the compiler route every loop exit through one
+        // flag-guarded block that also falls back into the loop header; that fake edge made it treat the
+        // registers of the chunk two steps back as still in flight and wait for ALL outstanding stores
+        // (vmcnt(0)) before issuing a step's pixel loads (tests/test_kernel_listing.py pins the fix).
+        const uint32_t lb_ok = __builtin_amdgcn_readfirstlane(sh.lb[par][2]);
         const uint32_t next_id = __builtin_amdgcn_readfirstlane(sh.lb[par][3]);
-        if (!lb_ok) return 2;
+        if (!lb_ok) {   // look-back time-out (sticky word already set): drop everything, finish empty
+            prev.valid = false;
+            cur.valid = cur.hasA = cur.hasB = false;
+            nxt.valid = nxt.hasA = nxt.hasB = false;
+        }
         uint32_t wbase = 0, cur_total = 0;
 #pragma unroll
         for (int k = 0; k < kEncWaves; k++) {
@@ -696,107 +676,13 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         prev_wtot = wtot;
         prev_total = cur_total;
         cur = nxt;
-        nxt = chunk_ref(p, next_id, tid);
-        return 1;
+        nxt = chunk_ref(p, lb_ok ? next_id : 0xFFFFFFFFu, tid);
     };
-    for (;;) {
-        int rc = step(0u, r0a, r0b, r1a, r1b);
-        if (rc != 1) break;
-        rc = step(1u, r1a, r1b, r0a, r0b);
-        if (rc != 1) break;
-    }
+    do {
+        step(0u, r0a, r0b, r1a, r1b);
+        step(1u, r1a, r1b, r0a, r0b);
+    } while (cur.valid || prev.valid);
 }
-
-// ---------------------------------------------------------------------------------------
-// ENCODE, frame-wise form: one workgroup owns whole frames (slot layout, many frames)
-// ---------------------------------------------------------------------------------------
-// With one output slot per frame (the reference's own semantics: dbde_pack_frame packs each
-// frame into its own target) frames do not depend on each other.  When the batch has at least
-// as many frames as the device holds workgroups, a workgroup simply walks its frames chunk by
-// chunk and carries the payload offset in a register: no tickets, no records, no scanner, no
-// waiting on any other workgroup (so nothing to prove about residency either).  Same per-chunk
-// pipeline as above: nxt's image loads in flight while cur is reduced, packed into the wave's
-// LDS region and stored; one workgroup barrier per chunk (the wave totals).
-template <int WAVES>
-struct EncSharedFW {
-    uint64_t pay[WAVES][kWaveWords + 64];   // + one trash word per lane (pack_two_tiles)
-    uint32_t tot[2][WAVES];
-};
-
-// One pipeline step of the frame-wise encoder: RC holds cur's pixels, RN receives nxt's.
-#define DBDE_FW_STEP(RCA, RCB, RNA, RNB)                                                                           \
-    {                                                                                                              \
-        const uint32_t par = it & 1u;                                                                              \
-        /* next chunk: same frame, or the first chunk of this workgroup's next frame */                            \
-        uint32_t nf = f, ncf = cf + 1u;                                                                            \
-        if (ncf == cpf) { ncf = 0; nf = f + gridDim.x; }                                                           \
-        const ChunkRef nxt = chunk_ref(p, nf < n_frames ? nf * cpf + ncf : 0xFFFFFFFFu, tid, WAVES * 128u);                      \
-        load_chunk<IN_MODE, false>(p, nxt, RNA, RNB);                                                              \
-        /* statistics (dbde_util.cpp:30-68) and offsets inside the wave */                                         \
-        uint32_t mnA, mxA, mnB, mxB;                                                                               \
-        load_fixup_generic<IN_MODE>(p, cur, RCA, RCB);                                                             \
-        tile_minmax(RCA, mnA, mxA);                                                                                \
-        tile_minmax(RCB, mnB, mxB);                                                                                \
-        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;                                             \
-        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;                                             \
-        const uint32_t incl = wave_scan_incl(dA + dB);                                                             \
-        const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);                                                 \
-        if (lane == 0) sh.tot[par][wave] = wtot;                                                                   \
-        __syncthreads();                                                                                           \
-        uint32_t wbase = 0, cur_total = 0;                                                                         \
-        _Pragma("unroll") for (int k = 0; k < WAVES; k++) {                                                        \
-            const uint32_t tk = sh.tot[par][k];                                                                    \
-            wbase += k < wave ? tk : 0u;                                                                           \
-            cur_total += tk;                                                                                       \
-        }                                                                                                          \
-        /* pack into the wave's LDS region, then LDS -> global (16 B per lane) */                                  \
-        if (wtot != 0u) {                                                                                          \
-            const uint32_t offA = incl - (dA + dB), offB = offA + dA;                                              \
-            const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB))); \
-            if (all8) {                                                                                            \
-                if (cur.hasA) pack_tile_d8(RCA, mnA, pay, offA);                                                   \
-                if (cur.hasB) pack_tile_d8(RCB, mnB, pay, offB);                                                   \
-            } else {                                                                                               \
-                pack_two_tiles(RCA, mnA, dA, offA, RCB, mnB, dB, offB, pay, kWaveWords + (uint32_t)lane);          \
-            }                                                                                                      \
-        }                                                                                                          \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                                     \
-        __builtin_amdgcn_wave_barrier();                                                                           \
-        store_wave_part<ALIGNED_OUT>(p, cur, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, inf, pay, lane); \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                                     \
-        __builtin_amdgcn_wave_barrier();                                                                           \
-        if (tid == 0 && (cf == 0u || cf == cpf - 1u)) scanner_frame_fields<ALIGNED_OUT>(p, f, cf, inf + cur_total, 0u); \
-        inf = ncf == 0u ? 0u : inf + cur_total;                                                                    \
-        f = nf; cf = ncf;                                                                                          \
-        cur = nxt;                                                                                                 \
-        it++;                                                                                                      \
-    }
-
-template <int IN_MODE, bool ALIGNED_OUT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 4) void encode_framewise_kernel(EncParams p) {
-    __shared__ __attribute__((aligned(16))) EncSharedFW<WAVES> sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t cpf = p.chunks_per_frame;
-    const uint32_t n_frames = p.n_chunks / cpf;
-    uint64_t *pay = sh.pay[wave];
-
-    uint32_t f = blockIdx.x, cf = 0;
-    if (f >= n_frames) return;
-    ChunkRef cur = chunk_ref(p, f * cpf, tid, WAVES * 128u);
-    uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { r0a[i] = 0; r0b[i] = 0; r1a[i] = 0; r1b[i] = 0; }   // lanes without tiles stay 0
-    load_chunk<IN_MODE, false>(p, cur, r0a, r0b);
-    uint32_t inf = 0;   // payload words of this frame before cur
-    uint32_t it = 0;
-    // two steps per trip with the register sets swapped: no copy between them
-    while (cur.valid) {
-        DBDE_FW_STEP(r0a, r0b, r1a, r1b)
-        if (!cur.valid) break;
-        DBDE_FW_STEP(r1a, r1b, r0a, r0b)
-    }
-}
-#undef DBDE_FW_STEP
 
 static int in_mode_of(const EncParams &p, bool fast_in) { return fast_in ? kInFast : (p.W >= 8 ? kInRaw : kInBytes); }
 
@@ -813,27 +699,6 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
         default: hipLaunchKernelGGL((encode_kernel<kInBytes, false>), grid, block, 0, s, p); break;
     }
     return hipGetLastError();
-}
-
-template <int WAVES>
-static hipError_t launch_fw(const EncParams &p, bool fast_in, bool aligned_out, uint32_t max_blocks, hipStream_t s) {
-    const uint32_t n_frames = p.n_chunks / p.chunks_per_frame;
-    dim3 block(64 * WAVES), grid(n_frames < max_blocks ? n_frames : max_blocks);
-    switch (in_mode_of(p, fast_in) * 2 + (aligned_out ? 1 : 0)) {
-        case kInFast * 2 + 1: hipLaunchKernelGGL((encode_framewise_kernel<kInFast, true, WAVES>), grid, block, 0, s, p); break;
-        case kInFast * 2 + 0: hipLaunchKernelGGL((encode_framewise_kernel<kInFast, false, WAVES>), grid, block, 0, s, p); break;
-        case kInRaw * 2 + 1: hipLaunchKernelGGL((encode_framewise_kernel<kInRaw, true, WAVES>), grid, block, 0, s, p); break;
-        case kInRaw * 2 + 0: hipLaunchKernelGGL((encode_framewise_kernel<kInRaw, false, WAVES>), grid, block, 0, s, p); break;
-        case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_framewise_kernel<kInBytes, true, WAVES>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((encode_framewise_kernel<kInBytes, false, WAVES>), grid, block, 0, s, p); break;
-    }
-    return hipGetLastError();
-}
-
-// p.chunks_per_frame / p.n_chunks must be in units of (waves * 128)-tile chunks.
-hipError_t launch_encode_framewise(const EncParams &p, int waves, bool fast_in, bool aligned_out, hipStream_t s) {
-    if (waves == 4) return launch_fw<4>(p, fast_in, aligned_out, p.grid_blocks * 2u, s);
-    return launch_fw<8>(p, fast_in, aligned_out, p.grid_blocks, s);
 }
 
 // Resident workgroups per CU of the encoder (occupancy query; LDS- and VGPR-bound).
@@ -875,7 +740,17 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
         const uint8_t *a_lo = darr - head;                                          // 16-byte aligned
         const uint32_t npieces = (head + T + 15u) >> 4;
         for (uint32_t i = tid; i < npieces; i += blockDim.x) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(a_lo + 16ull * i);
+            uint4 q;
+            if (a_lo + 16ull * (i + 1u) <= p.stream + p.stream_bytes) {
+                q = *reinterpret_cast<const uint4 *>(a_lo + 16ull * i);
+            } else {   // tiny frame at the very end of the extent (T < 7): the piece would cross it
+                uint32_t wq[4] = {0, 0, 0, 0};
+                for (uint32_t b = 0; b < 16u; b++) {
+                    const uint8_t *src = a_lo + 16ull * i + b;
+                    if (src < p.stream + p.stream_bytes) wq[b >> 2] |= (uint32_t)*src << (8u * (b & 3u));
+                }
+                q = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+            }
             const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
             // position of this piece's byte 0 relative to the array start
             const long long pos0 = 16ll * i - (long long)head;
@@ -1233,16 +1108,25 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
     // of the stream; the destination is wave-uniform base + lane*16, the permutation stays
     // inside one 256-byte group so the source side remains coalesced.  No staging registers.
     const uint32_t n16r = (n16 + 15u) & ~15u;
+    // Never read past the extent the caller declared (dbde_hip.h: stream_bytes is the READABLE extent): the
+    // whole-slot DMA stops before a slot that straddles the end; that slot (the last one of the last chunk
+    // of the last frame, at most) is fetched byte by byte below.
+    const uint8_t *s_end = p.stream + p.stream_bytes;
+    const uint32_t n16_dma = (asrc + 16ull * n16 <= s_end) ? n16 : n16 - 1u;
 #pragma unroll
     for (int j = 0; j < G::kPieces; j++) {
         const uint32_t i = (uint32_t)tid + (uint32_t)j * G::kThreads;
         const uint32_t src_slot = swz16(i);
-        if (i < n16r && src_slot < n16) {
+        if (i < n16r && src_slot < n16_dma) {
             const uint32_t wave_slot0 = (uint32_t)j * G::kThreads + (uint32_t)wave * 64u;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(asrc + 16ull * src_slot),
                 (__attribute__((address_space(3))) void *)(&s_in[2u * wave_slot0]), 16, 0, DBDE_NT ? 2 : 0);
         }
+    }
+    if (n16_dma != n16 && tid < 16) {   // the straddling slot, byte by byte: logical slot L lives at physical swz16(L)
+        const uint8_t *b = asrc + 16ull * n16_dma + (uint32_t)tid;
+        reinterpret_cast<uint8_t *>(s_in)[16u * swz16(n16_dma) + (uint32_t)tid] = b < s_end ? *b : (uint8_t)0;
     }
     uint32_t dA = 0, dB = 0, mA = 0, mB = 0;
     // t0 is even: when both byte arrays start at even addresses the lane's two tiles are one u16 each
@@ -1255,6 +1139,11 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
         if (hasB) { dB = depth_arr[t0 + 1]; mB = min_arr[t0 + 1]; }
     }
 
+    // The payload reaches LDS by DMA (and the tail bytes by ds_write); other waves read those slots after the
+    // barrier inside block_scan_incl.  A barrier does not drain vector memory: every wave must have seen its
+    // own DMA land (vmcnt) and its LDS writes retire (lgkmcnt) BEFORE it arrives at the barrier.  Stated
+    // explicitly instead of relying on where the compiler happens to put its waits.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     uint32_t chunk_total;   // equals chunk_words for a validated frame
     const uint32_t incl = block_scan_incl<G::kWaves>(dA + dB, s_wave_tot, lane, wave, chunk_total);   // barrier inside
     const uint32_t offA = incl - (dA + dB), offB = offA + dA;
@@ -1303,17 +1192,9 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
 }
 
 hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s) {
-    dim3 grid(p.n_chunks);
-    if (p.chunk_tiles == 256u) {
-        if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 256>), grid, dim3(128), 0, s, p);
-        else hipLaunchKernelGGL((decode_kernel<false, 256>), grid, dim3(128), 0, s, p);
-    } else if (p.chunk_tiles == 1024u) {
-        if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 1024>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((decode_kernel<false, 1024>), grid, dim3(512), 0, s, p);
-    } else {
-        if (fast_img) hipLaunchKernelGGL((decode_kernel<true, 512>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((decode_kernel<false, 512>), grid, dim3(256), 0, s, p);
-    }
+    dim3 grid(p.n_chunks), block(kChunkTiles / 2);
+    if (fast_img) hipLaunchKernelGGL((decode_kernel<true, (int)kChunkTiles>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((decode_kernel<false, (int)kChunkTiles>), grid, block, 0, s, p);
     return hipGetLastError();
 }
 

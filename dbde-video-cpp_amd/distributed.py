@@ -29,12 +29,12 @@ def _pieces(nbytes, piece):
     return [(at, min(piece, nbytes - at)) for at in range(0, nbytes, piece)]
 
 
-def gather_stream(segment, nbytes, dst=0, group=None, out=None, max_message_bytes=None):
-    """Gathers every rank's first `nbytes` bytes of `segment` (uint8, 1-D) to rank `dst`, in rank
-    order.  Returns (stream, sizes) on dst -- `stream` holds sum(sizes) bytes -- and (None, sizes)
-    elsewhere.  `out` may supply the destination buffer on dst (>= sum(sizes) bytes).  Segments
-    of many GB (1024 frames of 4096x3072 are 13 GB) are split into <= max_message_bytes pieces,
-    all posted in one group; both ends derive the same piece boundaries from the gathered sizes."""
+def gather_stream_begin(segment, nbytes, dst=0, group=None, out=None, max_message_bytes=None):
+    """Posts the variable-length gather of `segment[:nbytes]` (uint8, 1-D) to rank `dst` and returns
+    without waiting for the bytes: (stream_view_or_None, sizes, works).  The size exchange (a few bytes,
+    all_gather) is synchronous -- both ends need the sizes to post matching pieces -- the payload is not:
+    call gather_stream_end(works) before `segment` is overwritten or `out` is read.  This is what lets the
+    gather of batch k run beside the encode of batch k+1 (StreamEncoder below)."""
     piece = int(max_message_bytes or MAX_MESSAGE_BYTES)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -51,18 +51,31 @@ def gather_stream(segment, nbytes, dst=0, group=None, out=None, max_message_byte
         at, ops = 0, []
         for r in range(world):
             if r == rank:
-                out[at:at + sizes[r]].copy_(segment[:sizes[r]])
+                out[at:at + sizes[r]].copy_(segment[:sizes[r]], non_blocking=True)
             else:
                 for o, n in _pieces(sizes[r], piece):
                     ops.append(dist.P2POp(dist.irecv, out[at + o:at + o + n], r, group))
             at += sizes[r]
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
-            w.wait()
-        return out[:total], sizes
+        return out[:total], sizes, (dist.batch_isend_irecv(ops) if ops else [])
     ops = [dist.P2POp(dist.isend, segment[o:o + n], dst, group) for o, n in _pieces(sizes[rank], piece)]
-    for w in (dist.batch_isend_irecv(ops) if ops else []):
+    return None, sizes, (dist.batch_isend_irecv(ops) if ops else [])
+
+
+def gather_stream_end(works):
+    """Waits for the transfers posted by gather_stream_begin (on nccl: makes the current stream wait)."""
+    for w in works:
         w.wait()
-    return None, sizes
+
+
+def gather_stream(segment, nbytes, dst=0, group=None, out=None, max_message_bytes=None):
+    """Gathers every rank's first `nbytes` bytes of `segment` (uint8, 1-D) to rank `dst`, in rank
+    order.  Returns (stream, sizes) on dst -- `stream` holds sum(sizes) bytes -- and (None, sizes)
+    elsewhere.  `out` may supply the destination buffer on dst (>= sum(sizes) bytes).  Segments
+    of many GB (1024 frames of 4096x3072 are 13 GB) are split into <= max_message_bytes pieces,
+    all posted in one group; both ends derive the same piece boundaries from the gathered sizes."""
+    stream, sizes, works = gather_stream_begin(segment, nbytes, dst, group, out, max_message_bytes)
+    gather_stream_end(works)
+    return stream, sizes
 
 
 def scatter_stream(stream, frame_bytes, src=0, group=None, device=None, max_message_bytes=None):

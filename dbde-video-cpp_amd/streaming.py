@@ -1,0 +1,131 @@
+"""Streaming driver for long frame sequences (SURVEY.md 7 "HBM capacity at config 5", 8e).
+
+BASELINE configs[4] is a 10,000-frame 4096x3072 stream: 126 GB of pixels and up to 130 GB of DBDE bytes.
+It is never all resident: a rank walks ITS contiguous block of frames (distributed.shard_frames) in
+batches through two input slots and two stream slots, and three things overlap on separate HIP streams:
+
+    source stream : frames of batch k+2 are produced into the input slot batch k has just left
+    codec stream  : encode batch k+1 (-> concatenated .dbde body) and decode it back (the round trip)
+    comm stream   : the compressed bytes of batch k travel to the root (RCCL send/recv over xGMI,
+                    distributed.gather_stream_begin/_end), into one of two root windows
+
+The host never waits on the codec stream: the byte count of batch k (needed to post matching send/recv
+pieces) is read through a side stream that waits only on batch k's encode event, while batch k+1 is already
+queued.  There is no collective on the encode/decode path itself; frames are independent
+(dbde_util.cpp:137-180, 291-328 keep no state between frames).
+"""
+import time
+
+import torch
+
+from . import distributed as dd
+
+
+class RoundTripStream:
+    """Encode+decode `n_frames` frames [first_frame, first_frame + n_frames) in batches of `batch`.
+
+    codec   : dbde_video_cpp_amd.Codec bound to the stream the codec kernels run on
+    source  : callable(first_frame, n, out_tensor) that ENQUEUES the production of n frames on
+              `source_stream` (e.g. synth_frames of a second Codec created on that stream), or None to re-use
+              what is in the input slots (caller filled them: a ring of resident frames)
+    gather  : None | "nccl" | "host": send every batch's compressed bytes to rank 0 ("host": staged through
+              pinned memory, for gloo rehearsals)
+    """
+
+    def __init__(self, codec, W, H, batch, source=None, source_stream=None, gather=None, decode=True, check=False):
+        self.codec, self.W, self.H, self.batch = codec, W, H, batch
+        self.source, self.gather, self.decode, self.check = source, gather, decode, check
+        dev = codec.device
+        self.dev = dev
+        self.s_codec = codec.stream
+        self.s_src = source_stream if source_stream is not None else torch.cuda.Stream(dev)
+        self.s_comm = torch.cuda.Stream(dev)
+        self.s_copy = torch.cuda.Stream(dev)
+        self.inp = [torch.empty((batch, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.out = [codec.alloc_stream(W, H, batch) for _ in range(2)]            # (buf, lead, cap)
+        self.img = torch.empty((batch, H, W), dtype=torch.uint8, device=dev) if decode else None
+        self.offs = [torch.empty(batch, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.sizes = [torch.empty(batch, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.res = torch.empty((batch, 4), dtype=torch.int64, device=dev)
+        self.total_pinned = torch.empty(2, dtype=torch.int64).pin_memory()
+        self.ev_src = [torch.cuda.Event() for _ in range(2)]
+        self.ev_enc = [torch.cuda.Event() for _ in range(2)]
+        self.ev_gath = [torch.cuda.Event() for _ in range(2)]
+        self.ev_copy = torch.cuda.Event()
+        self.window = None
+        self.mismatches = 0
+
+    def _produce(self, slot, first, n):
+        if self.source is None:
+            return
+        with torch.cuda.stream(self.s_src):
+            self.s_src.wait_event(self.ev_enc[slot])      # the encode that read this slot has finished
+            self.source(first, n, self.inp[slot][:n])
+            self.ev_src[slot].record(self.s_src)
+
+    def _batch_bytes(self, slot, n):
+        """Compressed bytes of the batch in `slot`, read without touching the codec stream."""
+        with torch.cuda.stream(self.s_copy):
+            self.s_copy.wait_event(self.ev_enc[slot])
+            self.total_pinned[slot:slot + 1].copy_((self.offs[slot][n - 1:n] + self.sizes[slot][n - 1:n]), non_blocking=True)
+            self.ev_copy.record(self.s_copy)
+        self.ev_copy.synchronize()
+        return int(self.total_pinned[slot].item())
+
+    def _post_gather(self, slot, n, world, rank):
+        nbytes = self._batch_bytes(slot, n)
+        buf, lead, cap = self.out[slot]
+        seg = buf[lead:lead + cap]
+        if self.gather == "host":      # gloo rehearsal: CPU tensors, blocking
+            host = seg[:nbytes].cpu()
+            _, sizes = dd.gather_stream(host, nbytes, dst=0)
+            self.ev_gath[slot].record(self.s_comm)
+            return nbytes, sum(sizes)
+        with torch.cuda.stream(self.s_comm):
+            self.s_comm.wait_event(self.ev_enc[slot])
+            if rank == 0 and self.window is None:
+                self.window = [torch.empty(world * (cap + 64), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            _, sizes, works = dd.gather_stream_begin(seg, nbytes, dst=0, out=self.window[slot] if rank == 0 else None)
+            dd.gather_stream_end(works)
+            self.ev_gath[slot].record(self.s_comm)
+        return nbytes, sum(sizes)
+
+    def run(self, first_frame, n_frames, world=1, rank=0):
+        """Returns a dict: frames, seconds (host wall, everything drained), packed bytes of this rank,
+        gathered bytes (root's view of every rank) when gathering."""
+        codec, W, H, B = self.codec, self.W, self.H, self.batch
+        nb = (n_frames + B - 1) // B
+        count = lambda k: min(B, n_frames - k * B)
+        for ev in self.ev_enc + self.ev_gath:
+            ev.record(self.s_codec)
+        for k in range(min(2, nb)):
+            self._produce(k, first_frame + k * B, count(k))
+        packed = gathered = 0
+        torch.cuda.synchronize(self.dev)      # the first two batches are resident when the clock starts
+        t0 = time.perf_counter()
+        for k in range(nb):
+            slot, n = k % 2, count(k)
+            buf, lead, cap = self.out[slot]
+            with torch.cuda.stream(self.s_codec):
+                if self.source is not None:
+                    self.s_codec.wait_event(self.ev_src[slot])
+                self.s_codec.wait_event(self.ev_gath[slot])          # the gather that read this stream slot is done
+                codec.encode_frames(self.inp[slot], W, H, n, buf, lead, cap, first_index=first_frame + k * B,
+                                    offsets=self.offs[slot], nbytes=self.sizes[slot])
+                self.ev_enc[slot].record(self.s_codec)
+                if self.decode:
+                    codec.decode_frames(buf, lead, cap, self.offs[slot], W, H, n, images=self.img, results=self.res)
+                    if self.check:
+                        self.mismatches += int((self.img[:n] != self.inp[slot][:n]).any().item())
+            if k + 2 < nb:
+                self._produce(slot, first_frame + (k + 2) * B, count(k + 2))
+            if self.gather and k >= 1:
+                a, b = self._post_gather((k - 1) % 2, count(k - 1), world, rank)
+                packed, gathered = packed + a, gathered + b
+        if self.gather:
+            a, b = self._post_gather((nb - 1) % 2, count(nb - 1), world, rank)
+            packed, gathered = packed + a, gathered + b
+        torch.cuda.synchronize(self.dev)
+        dt = time.perf_counter() - t0
+        codec.sync()
+        return {"frames": n_frames, "batches": nb, "seconds": dt, "packed_bytes": packed, "gathered_bytes": gathered}

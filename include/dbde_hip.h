@@ -121,6 +121,12 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
  * whole frames found in *n_found (host).  Synchronous. */
 int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W,
                           int H, int max_frames, uint64_t *d_frame_offsets, int *n_found);
+/* The same walk, enqueued on the context's stream without waiting for it: the frame count lands in the
+ * DEVICE word *d_n_found.  A dbde_hip_decode_frames call enqueued behind it may use d_frame_offsets
+ * directly (a reader that knows how many frames it expects, or that bounds the decode by max_frames and
+ * inspects the per-frame results: entries past the count are left untouched). */
+int dbde_hip_index_stream_async(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W,
+                                int H, int max_frames, uint64_t *d_frame_offsets, uint32_t *d_n_found);
 
 /* Counter-based synthetic frames (same bytes as oracle/synth.c): mode 0 noise8, 1 mixed,
  * 2 flat, 3 smooth.  Used by bench.py and the parity tests to build inputs in HBM. */
@@ -206,9 +212,9 @@ void dbde_hip_reader_close(dbde_hip_reader *r);
 /* ---- kernel timing hook for bench.py ---------------------------------------------------- */
 /* When enabled, every encode / decode call brackets its kernels with HIP events on the
  * context's stream; dbde_hip_timing_read returns accumulated milliseconds and launch counts
- * ([0]=encode kernel, [1]=decode index kernel, [2]=decode kernel) after synchronising. */
+ * ([0]=encode kernel, [1]=decode index kernel, [2]=decode kernel, [3]=stream scanner) after synchronising. */
 int dbde_hip_timing_enable(dbde_hip_ctx *ctx, int on);
-int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[3], uint64_t launches[3], int reset);
+int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[4], uint64_t launches[4], int reset);
 
 #ifdef __cplusplus
 }

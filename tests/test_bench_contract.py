@@ -4,6 +4,8 @@ import glob
 import json
 import os
 import re
+import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -46,5 +48,37 @@ def test_bench_source_emits_the_contract_fields():
         assert '"%s"' % k in src, k
     # only the cpu_baseline leg may touch the oracle
     uses = [m.start() for m in re.finditer(r"oracle_ffi|Oracle\(|Reference\(", src)]
-    lo, hi = src.index("def cpu_baseline"), src.index("def main")
+    lo = src.index("def cpu_baseline")
+    hi = lo + re.search(r"\n(?:def|class) ", src[lo + 1:]).start()
     assert uses and all(lo <= u < hi for u in uses), "oracle used outside cpu_baseline"
+
+
+def run_bench(*argv, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                       env=e, timeout=300)
+    return r
+
+
+def test_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (the driver's command form, no launcher) must itself start two ranks: the
+    dry run exercises the spawn, the rendezvous on 127.0.0.1, sharding, barrier, max-over-ranks and the
+    variable-length gather over gloo -- everything around the GPU work -- and reports n_gpus from the group."""
+    r = run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["warmup"] == 1
+    assert d["frames_of_rank0"] == [0, 16] and d["gathered_bytes"] == 100 + 107
+    assert d["value"] == 0.0 and "dry run" in d["data"]
+
+
+def test_world_size_must_match_gpus_flag():
+    """Launched under a launcher with a different world size, bench.py refuses instead of mislabelling."""
+    e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, env=e, timeout=120)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr

@@ -138,15 +138,11 @@ def test_batch_encode_matches_oracle(codec, oracle, W, H, n, mode):
     imgs_h = imgs.cpu().numpy()
     import os
     slot_bytes = ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
-    # layouts: concatenated; one slot per frame (scanner path); one slot per frame, frame-wise kernel
-    for slot, framewise in ((0, False), (slot_bytes, False), (slot_bytes, True)):
+    # layouts: concatenated; one slot per frame
+    for slot in (0, slot_bytes):
         for misalign in (0, 3):
-            os.environ["DBDE_HIP_FRAMEWISE_MIN"] = "1" if framewise else "0"
-            try:
-                frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=100,
-                                                              slot_stride=slot, misalign=misalign)
-            finally:
-                os.environ.pop("DBDE_HIP_FRAMEWISE_MIN", None)
+            frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=100,
+                                                          slot_stride=slot, misalign=misalign)
             for f in range(n):
                 want = oracle.pack_frame(100 + f, imgs_h[f], W, H)
                 assert frames[f].tobytes() == want.tobytes(), (W, H, mode, slot, misalign, f)
@@ -232,6 +228,41 @@ def test_index_stream(codec):
     assert cnt == n and (found.cpu().numpy() == offs.cpu().numpy()).all()
     found, cnt = codec.index_stream(buf, lead, total - 1, W, H, 100)   # truncated last frame
     assert cnt == n - 1
+    # the asynchronous form: offsets and the device-side count, usable by a decode enqueued behind it
+    import torch
+    offs2 = torch.full((100,), -1, dtype=torch.int64, device=buf.device)
+    offs2, count = codec.index_stream_async(buf, lead, total, W, H, 100, offs2)
+    back, res = codec.decode_frames(buf, lead, total, offs2, W, H, n)
+    codec.sync()
+    assert int(count.item()) == n and torch.equal(offs2[:n], offs) and (offs2[n:] == -1).all()
+    assert torch.equal(back, imgs)
+
+
+@pytest.mark.parametrize("W,H,n,mode", [(200, 123, 3, "mixed"), (8, 8, 1, "noise8"), (9, 9, 2, "mixed"),
+                                        (4096, 24, 1, "noise8"), (1, 1, 1, "flat"), (24, 8, 1, "noise8")])
+def test_decode_reads_nothing_past_stream_bytes(codec, W, H, n, mode):
+    """dbde_hip.h: stream_bytes is the READABLE extent.  The stream is placed so that its end falls on
+    every residue mod 16 (the payload DMA moves whole 16-byte slots from an aligned-down source; the slot
+    that straddles the end must be fetched byte by byte), with different garbage behind it each time:
+    the decode must be identical, and the index/scan must accept exactly these bytes."""
+    import torch
+    imgs = codec.synth_frames(mode, SEED, 3, n, W, H)
+    frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=3)
+    total = int((offs[-1] + sizes[-1]).item())
+    for pad in range(16):
+        for junk in (0xA5, 0x00, 0xFF):
+            t = torch.full((pad + total + 48,), junk, dtype=torch.uint8, device=imgs.device)
+            t[pad:pad + total] = buf[lead:lead + total]
+            back, res = codec.decode_frames(t, pad, total, offs, W, H, n)
+            codec.sync()
+            assert torch.equal(back, imgs), (pad, junk)
+            assert all(r == (2, 3 + f, 0, len(frames[f])) for f, r in enumerate(codec.parse_results(res)))
+        # one byte short: the last frame no longer fits and is rejected, the others still decode
+        canvas = torch.full_like(imgs, 0xEE)
+        back, res = codec.decode_frames(t, pad, total - 1, offs, W, H, n, images=canvas)
+        codec.sync()
+        rr = codec.parse_results(res)
+        assert rr[-1][0] == 0xFFFFFFFF and (back[-1] == 0xEE).all() and torch.equal(back[:-1], imgs[:-1])
 
 
 @pytest.mark.parametrize("name", ["cfg2_4096x3072", "cfg3_2048x2048", "cfg4_1921x1081"])
@@ -281,9 +312,10 @@ def test_large_batch_properties(codec, oracle):
         del imgs, buf, back
 
 
-def test_framewise_many_frames(codec, oracle):
-    """Slot layout with more frames than resident workgroups: the frame-wise kernel (a workgroup
-    owns whole frames, several in a row), against the oracle and round trip."""
+def test_slots_many_frames(codec, oracle):
+    """Slot layout with more frames than resident workgroups (every persistent encoder workgroup walks
+    many frames; the decode index takes its one-workgroup-per-frame form from 256 frames on), against
+    the oracle and round trip."""
     import torch
     for (W, H, n, mode) in [(1024, 768, 1300, "mixed"), (333, 200, 700, "smooth"), (2048, 2048, 520, "noise8")]:
         imgs = codec.synth_frames(mode, SEED, 7, n, W, H)

@@ -1,0 +1,106 @@
+"""CPU, compile only: static checks on the gfx950 listing of the kernels (`make asm`, no GPU).
+
+The persistent encoder keeps the NEXT chunk's eight 16-byte pixel loads in flight while it reduces the
+CURRENT chunk, whose pixels were requested one step earlier.  Hardware retires a wave's vector-memory
+operations through one in-order counter, and the compiler places `s_waitcnt vmcnt(N)` from a STATIC count of
+what was issued after the value it needs.  Two things can silently go wrong when the kernel is edited:
+
+  * the loads of a step are issued conditionally (or behind a branch merge): the compiler can no longer
+    count them and waits for everything -> the software pipeline overlaps nothing (that
+    cost 5 points of roofline before it was found);
+  * a statically countable number of stores lands between a chunk's loads and their use: the waits become
+    LOOSER than the number of loads (vmcnt(23) ...), and the kernel then depends on stores and loads
+    retiring strictly in issue order.  An experiment of round 1 that did exactly that produced wrong payload
+    bytes once in a few hundred chunks.
+
+Both show in the listing: in the steady-state loop every group of eight pixel loads must be followed by the
+waits vmcnt(15), vmcnt(14), ..., vmcnt(8) -- exactly the eight loads just issued stay outstanding, nothing
+else is assumed about younger operations.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "dbde-video-cpp_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def listing():
+    r = subprocess.run(["make", "-s", "-C", CSRC, "asm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(os.path.join(CSRC, "dbde_kernels.s")).read()
+
+
+def function_body(listing, mangled):
+    m = re.search(r"^%s:[^\n]*\n(.*?)\n\.Lfunc_end" % re.escape(mangled), listing, re.S | re.M)
+    assert m, f"{mangled} not in the listing"
+    return m.group(1).splitlines()
+
+
+def pixel_load_groups(lines):
+    """[(index of the last load, [vmcnt immediates up to the next barrier])] for every group of eight
+    non-temporal 16-byte loads (a step's pixel fetch; a few address instructions may sit between them)."""
+    idx = [i for i, ln in enumerate(lines)
+           if ln.strip().startswith("global_load_dwordx4") and ln.strip().endswith("nt")]
+    groups, cur = [], []
+    for i in idx:
+        if cur and i - cur[-1] > 12:
+            groups.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    out = []
+    for g in groups:
+        assert len(g) == 8, f"a pixel fetch of {len(g)} loads at listing line {g[0]}: expected 8 per step"
+        waits = []
+        for ln in lines[g[-1] + 1:]:
+            t = ln.strip()
+            if t.startswith("s_barrier"):
+                break
+            m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", t)
+            if m:
+                waits.append(int(m.group(1)))
+        out.append((g[-1], waits))
+    return out
+
+
+@pytest.mark.parametrize("mangled", ["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE",
+                                     "_ZN4dbde13encode_kernelILi0ELb0EEEvNS_9EncParamsE"])
+def test_fast_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing, mangled):
+    lines = function_body(listing, mangled)
+    groups = pixel_load_groups(lines)
+    steady = [(i, w) for i, w in groups if w]   # the prologue's group meets a barrier first (drained behind it)
+    assert len(steady) == 2, f"expected the two unrolled pipeline steps, found {len(steady)} ({groups})"
+    for last, w in steady:
+        assert w[:8] == [15, 14, 13, 12, 11, 10, 9, 8], (
+            f"pixel waits are {w[:8]}: looser than 15..8 means younger stores are being counted on to retire in "
+            f"order; tighter means the prefetch no longer overlaps the statistics")
+        # the straight-line block that computes the addresses and issues the loads (everything after the last
+        # label) must not wait on vector memory: a vmcnt there means every wave drains its previous stores
+        # before it may prefetch (the fake loop edge described in encode_kernel)
+        first = last
+        while first > 0 and not lines[first - 1].startswith(".LBB"):
+            first -= 1
+        block = [ln.strip() for ln in lines[first:last + 1]]
+        assert sum(b.startswith("global_load_dwordx4") for b in block) == 8, "load group is not one straight-line block"
+        assert not [b for b in block if re.match(r"s_waitcnt.*vmcnt", b)], \
+            f"vector-memory wait in front of the prefetch: {[b for b in block if b.startswith('s_waitcnt')]}"
+
+
+def test_no_scratch_and_expected_occupancy(listing):
+    """The hot kernels must not spill and must keep the residency the design assumes: encoder <= 128 VGPRs
+    (2 workgroups of 8 waves per CU), decoder <= 64 VGPRs (8 waves per SIMD allowed by registers)."""
+    meta = {}
+    md = listing[listing.index("amdhsa.kernels:"):]
+    for entry in re.split(r"\n  - \.", md)[1:]:   # one YAML list item per kernel
+        get = lambda k: re.search(r"\.?%s:\s+(\S+)" % k, entry).group(1)
+        meta[get("name")] = {"vgpr": int(get("vgpr_count")), "scratch": int(get("private_segment_fixed_size")),
+                             "lds": int(get("group_segment_fixed_size"))}
+    enc = meta["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE"]
+    assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, enc
+    dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILb1E")]
+    assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 64 for d in dec), dec

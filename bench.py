@@ -75,36 +75,65 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def host_cores():
+    """(cores this process may really use, cores visible): the affinity mask capped by the cgroup CPU quota
+    (a GPU box hands a 1-GPU job a share of the host, e.g. 16 of 256 hardware threads)."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // period)
+        except Exception:
+            pass
+    return (min(visible, quota) if quota else visible), visible
+
+
+def progress(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(make_frames, W, H, budget_s=12.0):
-    """Reference (oracle/_ref, kind 'reference') or oracle port on ALL host cores: every thread round-trips
-    its own frame; bounded to about `budget_s` seconds of wall time."""
+    """Reference (oracle/_ref, kind 'reference') or oracle port on ALL the host cores this job may use: every
+    thread round-trips its own frame until `budget_s` seconds of wall time have passed."""
     from oracle_ffi import Oracle, Reference
     impl, kind = (Reference(), "reference") if Reference.available() else (Oracle(), "port")
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores, visible = host_cores()
     n_distinct = min(cores, 32)
     images_host = make_frames(n_distinct)
     t1 = impl.time_roundtrip(images_host[0:1], 1, W, H, 1)[0]   # calibrate on one frame, one thread
-    reps = max(1, int(budget_s / max(t1, 1e-4)))
-    results = [None] * cores
+    chunk = max(1, int(0.5 / max(t1, 1e-4)))                    # round trips per call (about half a second)
+    done = [0] * cores
+    bad = [0] * cores
+    deadline = time.time() + budget_s
 
     def work(k):
         j = k % n_distinct
-        results[k] = impl.time_roundtrip(images_host[j:j + 1], 1, W, H, reps)
+        while time.time() < deadline:
+            r = impl.time_roundtrip(images_host[j:j + 1], 1, W, H, chunk)
+            done[k] += chunk
+            bad[k] += r[3]
 
     t0 = time.time()
     th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
     [t.start() for t in th]
     [t.join() for t in th]
     wall = time.time() - t0
-    bad = sum(r[3] for r in results)
-    frames = cores * reps
+    frames = sum(done)
     return {"value": round(frames / wall, 2), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": f"{cores} threads (all host cores) x {reps} round trips of one {W}x{H} frame each "
-                      f"({frames} total, {wall:.1f} s wall)",
-            "single_thread_frames_per_s": round(1.0 / t1, 2), "mismatched_pixels": int(bad)}
+            "host_cores_visible": visible,
+            "sample": f"{cores} threads (every core this job may use; {visible} visible) round-tripping one "
+                      f"{W}x{H} noise8 frame each for {wall:.1f} s ({frames} round trips)",
+            "single_thread_frames_per_s": round(1.0 / t1, 2), "mismatched_pixels": int(sum(bad))}
 
 
 class Bench:
@@ -124,6 +153,8 @@ class Bench:
         """Times `steps` encode+decode passes over B frames.  layout: 'slots' | 'concat' | 'concat+scan'
         (decode from the offsets the device stream scanner finds, not from the encoder's)."""
         torch, dv, codec, rank = self.torch, self.dv, self.codec, self.rank
+        if rank == 0:
+            progress(f"case {W}x{H} x{B} {content} {layout}: {steps} steps")
         imgs = codec.synth_frames(content, SEED, rank * B, B, W, H)
         slot = ((dv.max_frame_bytes(W, H) + 255) // 256) * 256 if layout == "slots" else 0
         buf, lead, cap = codec.alloc_stream(W, H, B, slot_stride=slot)
@@ -197,6 +228,7 @@ class Bench:
     def single_frame(self, W, H, content, reps=300):
         """configs[1] literally: ONE frame per encode+decode call, device-resident, back to back."""
         torch, dv, codec = self.torch, self.dv, self.codec
+        progress(f"single frame {W}x{H} {content}")
         one = codec.synth_frames(content, SEED, 0, 1, W, H)
         buf, lead, cap = codec.alloc_stream(W, H, 1)
         out = torch.empty_like(one)
@@ -238,6 +270,8 @@ class Bench:
         for name, g in (("kernels_only", None), ("with_gather", gather_mode)):
             if name == "with_gather" and g is None:
                 continue
+            if self.rank == 0:
+                progress(f"stream {W}x{H} {n_total} frames in batches of {batch}, {content}, {name}")
             rts = RoundTripStream(self.codec, W, H, batch, source=source, source_stream=side, gather=g)
             self.fence()
             r = rts.run(lo, hi - lo, self.world, self.rank)
@@ -423,6 +457,7 @@ def main():
 
     if rank == 0:
         if not args.no_cpu and world == 1 and not args.only:
+            progress("cpu baseline")
             mk = lambda n: b.codec.synth_frames("noise8", SEED, 0, n, 4096, 3072).cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(mk, 4096, 3072)
         print(json.dumps(line), flush=True)

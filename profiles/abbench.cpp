@@ -1,0 +1,110 @@
+// abbench.cpp -- A/B timing of libdbde_hip.so builds through the C-ABI, without Python (no torch import:
+// a variant costs seconds, so one GPU call can rank many).  Build: hipcc --offload-arch=gfx950 -O2
+// profiles/abbench.cpp -o profiles/abbench -ldl.  Usage:
+//   abbench <libdbde_hip.so> <W> <H> <frames> <noise8|mixed|flat|smooth> <slots|concat> <steps> [tag]
+// Prints one JSON line: kernel times from the library's own HIP-event hook, round trip verified on the device.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define CK(x)                                                                                  \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } \
+    } while (0)
+
+__global__ void count_diff(const uint4 *a, const uint4 *b, size_t n16, unsigned long long *out) {
+    unsigned long long d = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 x = a[i], y = b[i];
+        d += (x.x != y.x) + (x.y != y.y) + (x.z != y.z) + (x.w != y.w);
+    }
+    if (d) atomicAdd(out, d);
+}
+
+typedef struct ctx ctx;
+int main(int argc, char **argv) {
+    if (argc < 8) { fprintf(stderr, "usage: abbench lib W H frames content layout steps [tag]\n"); return 1; }
+    const char *libpath = argv[1];
+    const int W = atoi(argv[2]), H = atoi(argv[3]), B = atoi(argv[4]), steps = atoi(argv[7]);
+    const char *content = argv[5];
+    const bool slots = strcmp(argv[6], "slots") == 0;
+    const char *tag = argc > 8 ? argv[8] : libpath;
+    int mode = !strcmp(content, "noise8") ? 0 : !strcmp(content, "mixed") ? 1 : !strcmp(content, "flat") ? 2 : 3;
+    void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+    using fn_dbde_hip_create = int (*)(int, void *, ctx **);
+    using fn_dbde_hip_destroy = void (*)(ctx *);
+    using fn_dbde_hip_sync = int (*)(ctx *);
+    using fn_dbde_hip_last_error = const char *(*)(ctx *);
+    using fn_dbde_hip_max_frame_bytes = size_t (*)(int, int);
+    using fn_dbde_hip_synth_frames = int (*)(ctx *, int, uint64_t, uint64_t, int, int, int, uint8_t *);
+    using fn_dbde_hip_encode_frames = int (*)(ctx *, const uint8_t *, int, int, int, uint64_t, const uint64_t *,
+                                              const uint64_t *, uint8_t *, size_t, uint64_t, uint64_t *, uint64_t *);
+    using fn_dbde_hip_decode_frames = int (*)(ctx *, const uint8_t *, size_t, const uint64_t *, int, int, int, uint8_t *, void *);
+    using fn_dbde_hip_timing_enable = int (*)(ctx *, int);
+    using fn_dbde_hip_timing_read = int (*)(ctx *, double *, uint64_t *, int);
+#define SYM(name) fn_##name name = (fn_##name)dlsym(h, #name); if (!name) { fprintf(stderr, "missing %s\n", #name); return 1; }
+    SYM(dbde_hip_create) SYM(dbde_hip_destroy) SYM(dbde_hip_sync) SYM(dbde_hip_last_error) SYM(dbde_hip_max_frame_bytes)
+    SYM(dbde_hip_synth_frames) SYM(dbde_hip_encode_frames) SYM(dbde_hip_decode_frames) SYM(dbde_hip_timing_enable)
+    SYM(dbde_hip_timing_read)
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    ctx *c = nullptr;
+    if (dbde_hip_create(0, s, &c) != 0) { fprintf(stderr, "create failed\n"); return 1; }
+    const size_t px = (size_t)W * H, maxf = dbde_hip_max_frame_bytes(W, H);
+    const size_t slot = slots ? (maxf + 255) / 256 * 256 : 0;
+    const size_t cap = slots ? (size_t)(B - 1) * slot + maxf : (size_t)B * maxf;
+    uint8_t *img, *out, *buf;
+    uint64_t *offs, *sizes;
+    unsigned long long *diff;
+    CK(hipMalloc(&img, px * B + 64));
+    CK(hipMalloc(&out, px * B + 64));
+    CK(hipMalloc(&buf, cap + 128));
+    CK(hipMalloc(&offs, 8 * (size_t)B));
+    CK(hipMalloc(&sizes, 8 * (size_t)B));
+    CK(hipMalloc(&diff, 8));
+    CK(hipMemsetAsync(diff, 0, 8, s));
+    CK(hipMemsetAsync(out, 0xEE, px * B, s));
+    if (dbde_hip_synth_frames(c, mode, 0xDBDE2016ull, 0, B, W, H, img)) { fprintf(stderr, "synth: %s\n", dbde_hip_last_error(c)); return 1; }
+    auto step = [&]() -> int {
+        if (dbde_hip_encode_frames(c, img, W, H, B, 0, nullptr, nullptr, buf + 32, cap, slot, offs, sizes)) return 1;
+        if (dbde_hip_decode_frames(c, buf + 32, cap, offs, W, H, B, out, nullptr)) return 1;
+        return 0;
+    };
+    for (int i = 0; i < 2; i++) if (step()) { fprintf(stderr, "step: %s\n", dbde_hip_last_error(c)); return 1; }
+    if (dbde_hip_sync(c)) { fprintf(stderr, "sync: %s\n", dbde_hip_last_error(c)); return 1; }
+    hipLaunchKernelGGL(count_diff, dim3(2048), dim3(256), 0, s, (const uint4 *)img, (const uint4 *)out, px * B / 16, diff);
+    unsigned long long hdiff = 0;
+    CK(hipMemcpyAsync(&hdiff, diff, 8, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    uint64_t *hs = (uint64_t *)malloc(8 * (size_t)B);
+    CK(hipMemcpy(hs, sizes, 8 * (size_t)B, hipMemcpyDeviceToHost));
+    double packed = 0;
+    for (int i = 0; i < B; i++) packed += (double)hs[i];
+    dbde_hip_timing_enable(c, 1);
+    double ms[4] = {0, 0, 0, 0};
+    uint64_t n[4] = {0, 0, 0, 0};
+    dbde_hip_timing_read(c, ms, n, 1);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < steps; i++) if (step()) return 1;
+    if (dbde_hip_sync(c)) { fprintf(stderr, "sync: %s\n", dbde_hip_last_error(c)); return 1; }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ms[3] = 0; n[3] = 0;
+    dbde_hip_timing_read(c, ms, n, 1);
+    const double alg = (double)px * B + packed;
+    const double enc = ms[0] / (n[0] ? n[0] : 1), idx = ms[1] / (n[1] ? n[1] : 1), dec = ms[2] / (n[2] ? n[2] : 1);
+    printf("{\"tag\": \"%s\", \"W\": %d, \"H\": %d, \"frames\": %d, \"content\": \"%s\", \"layout\": \"%s\", \"steps\": %d, "
+           "\"enc_ms\": %.4f, \"idx_ms\": %.4f, \"dec_ms\": %.4f, \"enc_frac\": %.4f, \"dec_frac\": %.4f, "
+           "\"wall_ms_per_step\": %.4f, \"fps\": %.1f, \"packed_over_raw\": %.4f, \"diff_dwords\": %llu}\n",
+           tag, W, H, B, content, slots ? "slots" : "concat", steps, enc, idx, dec, alg / (enc * 1e-3) / 8e12,
+           alg / (dec * 1e-3) / 8e12, wall / steps * 1e3, B * steps / wall, packed / ((double)px * B), hdiff);
+    fflush(stdout);
+    dbde_hip_destroy(c);
+    return hdiff ? 3 : 0;
+}

@@ -285,7 +285,11 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.n_chunks = n_chunks;
     p.flags = ctx->exp_flags;
     p.grid_blocks = ctx->enc_grid;
-    const bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
+    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
+    bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
+#ifdef DBDE_FORCE_GENERIC   // A/B builds only: the any-geometry kernels on aligned images
+    fast_in = false;
+#endif
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);
     HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
@@ -362,7 +366,10 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.T = g.T;
     p.chunks_per_frame = dcpf;
     p.n_chunks = (uint32_t)n_chunks64;
-    const bool fast_img = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
+    bool fast_img = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
+#ifdef DBDE_FORCE_GENERIC
+    fast_img = false;
+#endif
     span_begin(ctx, 2);
     HIP_TRY(ctx, launch_decode(p, fast_img, ctx->stream));
     span_end(ctx);
@@ -580,6 +587,17 @@ dbde_hip_video_header dbde_hip_unpack_video_header(uint8_t **packed) {
 }
 
 // ---- timing ----------------------------------------------------------------------------------
+
+// Diagnostic builds (-DDBDE_DIAG) accumulate in-kernel cycle counters; this reads (and clears) them.
+// Not part of include/dbde_hip.h: tuning tool (profiles/abbench.cpp) only.
+int dbde_hip_diag_read(dbde_hip_ctx *ctx, uint64_t out[16]) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->diag, 128, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->diag, 0, 128, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DBDE_HIP_OK;
+}
+
 
 int dbde_hip_timing_enable(dbde_hip_ctx *ctx, int on) {
     if (!ctx) return DBDE_HIP_ERR_ARG;

@@ -42,6 +42,7 @@ struct EncParams {
     uint32_t chunks_per_frame, n_chunks;
     uint32_t flags;                // bit 0: force ticket mode (A/B measurements)
     uint32_t grid_blocks;          // resident workgroups of the persistent encoder
+    unsigned long long *diag;      // [16] cycle counters, written only by -DDBDE_DIAG builds (profiles/variants.sh)
 };
 
 struct DecParams {

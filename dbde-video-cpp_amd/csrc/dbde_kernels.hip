@@ -19,6 +19,9 @@
 
 #include "dbde_bits.h"
 
+#ifndef DBDE_POLL
+#define DBDE_POLL 0   // where the encoder polls its mailbox (0 = round-1 order, A/B builds only)
+#endif
 #ifndef DBDE_NT
 #define DBDE_NT 1   // non-temporal hint on the streamed-once traffic (pixels, payload, decoded images)
 #endif
@@ -159,15 +162,14 @@ __device__ __forceinline__ void load_tile_generic(const uint8_t *img, int W, int
 // each record with its INC form.  A chunk's scout only polls its own 8-byte record.  This
 // moves >100 chunks/us with a few KB of polling per round, where a decoupled look-back (every
 // chunk re-reading a window of predecessors until it meets an INC) advanced only one window
-// per hop latency and flooded the fabric with polls.  While passing, the scanner also writes
-// what depends only on prefixes: frame header, the I32 fields, per-frame offsets and sizes.
+// per hop latency and flooded the fabric with polls.
 //
 // Records (8 B, relaxed agent-scope atomics, the record is its own flag):
 //   AGG : [63:62] = 1, [31:0] payload words of the chunk
 //   INC : [63:62] = 2, [61:32] payload words of the frame up to and including the chunk,
 //                      [31:0]  payload words of the launch up to and including it (mod 2^32)
 template <bool ALIGNED_OUT>
-__device__ __forceinline__ void scanner_frame_fields(const EncParams &p, uint32_t f, uint32_t cf, uint32_t inf_incl,
+__device__ __forceinline__ void write_frame_fields(const EncParams &p, uint32_t f, uint32_t cf, uint32_t inf_incl,
                                                      uint32_t frame_start_glob) {
     const uint64_t meta = 32ull + 2ull * p.T;
     const uint64_t frame_base = p.slot_stride ? (uint64_t)f * p.slot_stride
@@ -200,7 +202,10 @@ __device__ __forceinline__ void scanner_frame_fields(const EncParams &p, uint32_
     }
 }
 
-constexpr int kScanLoads = 8;   // records per lane per round (512 per round)
+#ifndef DBDE_SCAN_LOADS
+#define DBDE_SCAN_LOADS 8
+#endif
+constexpr int kScanLoads = DBDE_SCAN_LOADS;   // records per lane per round (64 x this many per round)
 
 template <bool ALIGNED_OUT>
 __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
@@ -209,6 +214,10 @@ __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
     uint32_t carry_glob = 0;           // launch-wide payload words before record F
     uint32_t frame_start_glob = 0;     // launch-wide payload words before the frame that contains record F
     uint64_t t_progress = wall_clock64();
+#ifdef DBDE_DIAG
+    const uint64_t dg_t0 = __builtin_amdgcn_s_memtime();
+    uint64_t dg_rounds = 0, dg_idle = 0, dg_conv_calls = 0;
+#endif
     while (F < p.n_chunks) {
         u64a w[kScanLoads];
 #pragma unroll
@@ -241,9 +250,6 @@ __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
                     if (act) {
                         const u64a rec = kStInc | ((u64a)(inf_incl & 0x3FFFFFFFu) << 32) | (u64a)g_incl;
                         __hip_atomic_store(&p.state[idx], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint32_t cf = idx - fstart;
-                        if (cf == 0u || cf == p.chunks_per_frame - 1u)
-                            scanner_frame_fields<ALIGNED_OUT>(p, f, cf, inf_incl, gs);
                     }
                     // carries for the record after the last converted one
                     const uint32_t last = cnt - 1u;
@@ -258,6 +264,11 @@ __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
                 if (cnt < 64u) stop = true;
             }
         }
+#ifdef DBDE_DIAG
+        dg_rounds++;
+        dg_idle += done ? 0 : 1;
+        dg_conv_calls += done;
+#endif
         if (done) {
             F += done;
             t_progress = wall_clock64();
@@ -269,12 +280,22 @@ __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
             __builtin_amdgcn_s_sleep(4);
         }
     }
+#ifdef DBDE_DIAG
+    if (lane == 0) {
+        atomicAdd(&p.diag[3], dg_rounds);
+        atomicAdd(&p.diag[4], dg_idle);
+        atomicAdd(&p.diag[5], __builtin_amdgcn_s_memtime() - dg_t0);
+        atomicAdd(&p.diag[6], dg_conv_calls);
+    }
+#endif
 }
 
 // Scout side: wait until the scanner has converted this chunk's own record.
-__device__ __forceinline__ bool wait_inc(const u64a *state, uint32_t c, uint32_t &inf_incl, uint32_t &glob_incl) {
+__device__ __forceinline__ bool wait_inc(const u64a *state, uint32_t c, uint32_t &inf_incl, uint32_t &glob_incl,
+                                         uint32_t *n_polls = nullptr) {
     const uint64_t t_start = wall_clock64();
     for (uint32_t spins = 0;; spins++) {
+        if (n_polls) *n_polls = spins + 1u;
         const u64a w = __hip_atomic_load(&state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t st = (uint32_t)(w >> 62);
         if (st == 2u) {
@@ -443,6 +464,11 @@ __device__ __forceinline__ uint64_t pack_row_dot(uint32_t lo, uint32_t hi, uint3
 // wave's LDS region starting at word q.
 __device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, uint32_t d, uint64_t *pay, uint32_t q) {
     const uint32_t m4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
+#ifdef DBDE_EXP_NOPACK   // A/B only (wrong bytes): what the bit packing costs
+#pragma unroll
+    for (int r = 0; r < 8; r++) if ((uint32_t)r < d) pay[swzq8(q + (uint32_t)r)] = ((uint64_t)(v[2 * r + 1] - m4) << 32) | (v[2 * r] - m4);
+    return;
+#endif
     const uint32_t w_lo = 1u | ((1u << d) << 8), w_hi = w_lo << 16;
     const bool is8 = d >= 8u;
     Funnel fn;
@@ -574,6 +600,10 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     ChunkRef prev = chunk_ref(p, 0xFFFFFFFFu, tid);
     uint64_t *pay = sh.pay[wave];
     uint32_t prev_meta = 0, prev_wbase = 0, prev_wtot = 0, prev_total = 0;
+#ifdef DBDE_DIAG
+    uint64_t dg_wait = 0, dg_nwait = 0, dg_bar = 0, dg_npoll = 0, dg_first = 0;
+    const uint64_t dg_k0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // One pipeline step.  `ca/cb` hold the pixels of cur (loaded one step ago), `na/nb` receive
     // those of nxt; the caller alternates the two register sets instead of copying them, so the
@@ -588,49 +618,92 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     auto step = [&](const uint32_t par, uint32_t (&ca)[16], uint32_t (&cb)[16], uint32_t (&na)[16],
                     uint32_t (&nb)[16]) __attribute__((always_inline)) -> void {
 
-        // ---- 1. mailbox of prev and the next ticket, before this iteration's loads --------------
-        if (tid == 0) {
-            uint32_t inf = 0, glob = 0, ok = 1u;
-            if (prev.valid) {
-                uint32_t inf_incl = 0, glob_incl = 0;
-                ok = wait_inc(p.state, prev.c, inf_incl, glob_incl) ? 1u : 0u;
-                inf = inf_incl - prev_total;
-                glob = glob_incl - prev_total;
-                if (!ok) atomicOr(p.sticky, 1u);
+        // ---- mailbox of prev (its prefixes, needed by the stores behind the barrier) and the next ticket ----
+        auto mailbox = [&]() __attribute__((always_inline)) {
+            if (tid == 0) {
+                uint32_t inf = 0, glob = 0, ok = 1u;
+                if (prev.valid) {
+                    uint32_t inf_incl = 0, glob_incl = 0;
+#ifdef DBDE_DIAG
+                    const uint64_t dg_w0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef DBDE_DIAG
+                    uint32_t dg_polls = 0;
+                    ok = wait_inc(p.state, prev.c, inf_incl, glob_incl, &dg_polls) ? 1u : 0u;
+                    dg_wait += __builtin_amdgcn_s_memtime() - dg_w0;
+                    dg_nwait++;
+                    dg_npoll += dg_polls;
+                    dg_first += dg_polls == 1u ? 1u : 0u;
+#else
+                    ok = wait_inc(p.state, prev.c, inf_incl, glob_incl) ? 1u : 0u;
+#endif
+                    inf = inf_incl - prev_total;
+                    glob = glob_incl - prev_total;
+                    if (!ok) atomicOr(p.sticky, 1u);
+                }
+                uint32_t tnew = 0xFFFFFFFFu;   // id of the chunk after nxt
+                if (nxt.valid) tnew = static_mode ? nxt.c + G : atomicAdd(&p.ctrl[2], 1u);
+                sh.lb[par][0] = inf;
+                sh.lb[par][1] = glob;
+                sh.lb[par][2] = ok;
+                sh.lb[par][3] = tnew;
             }
-            uint32_t tnew = 0xFFFFFFFFu;   // id of the chunk after nxt
-            if (nxt.valid) tnew = static_mode ? nxt.c + G : atomicAdd(&p.ctrl[2], 1u);
-            sh.lb[par][0] = inf;
-            sh.lb[par][1] = glob;
-            sh.lb[par][2] = ok;
-            sh.lb[par][3] = tnew;
-        }
-        // ---- 2. image loads of nxt (consumed when the pipeline rotates) --------------------------
-        load_chunk<IN_MODE>(p, nxt, na, nb);
-
-        // ---- 3. statistics of cur (dbde_util.cpp:30-68), offsets inside the wave, AGG -------------
-        uint32_t mnA, mxA, mnB, mxB;
-        load_fixup_generic<IN_MODE>(p, cur, ca, cb);
-        tile_minmax(ca, mnA, mxA);
-        tile_minmax(cb, mnB, mxB);
-        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
-        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
-        const uint32_t incl = wave_scan_incl(dA + dB);
-        const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
-        if (lane == 0) {
-            sh.tot[par][wave] = wtot;
-            // The last wave to get here publishes the chunk's AGG record at once: it never waits
-            // for a barrier or for the scanner.
-            const uint32_t old = atomicAdd(&sh.acc[par], (1u << 24) | wtot);
-            if ((old >> 24) == (uint32_t)(kEncWaves - 1)) {
-                sh.acc[par] = 0;   // next used two iterations from now
-                if (cur.valid) {
-                    const uint32_t total = (old & 0xFFFFFFu) + wtot;
-                    __hip_atomic_store(&p.state[cur.c], kStAgg | (u64a)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // ---- statistics of cur (dbde_util.cpp:30-68), offsets inside the wave, AGG ---------------------------
+        uint32_t mnA, mxA, mnB, mxB, dA, dB, incl, wtot;
+        auto statistics = [&]() __attribute__((always_inline)) {
+            load_fixup_generic<IN_MODE>(p, cur, ca, cb);
+            tile_minmax(ca, mnA, mxA);
+            tile_minmax(cb, mnB, mxB);
+            dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
+            dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
+            incl = wave_scan_incl(dA + dB);
+            wtot = __builtin_amdgcn_readlane(incl, 63);
+            if (lane == 0) {
+                sh.tot[par][wave] = wtot;
+                // The last wave to get here publishes the chunk's AGG record at once: it never waits
+                // for a barrier or for the scanner.
+                const uint32_t old = atomicAdd(&sh.acc[par], (1u << 24) | wtot);
+                if ((old >> 24) == (uint32_t)(kEncWaves - 1)) {
+                    sh.acc[par] = 0;   // next used two iterations from now
+                    if (cur.valid) {
+                        const uint32_t total = (old & 0xFFFFFFu) + wtot;
+                        __hip_atomic_store(&p.state[cur.c], kStAgg | (u64a)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
+        };
+        // Order.  The chunk's AGG record must not wait for anything: the scanner's answer to it (its INC
+        // record) is what the workgroup needs one step from now, and the scanner takes 3-5 us to give it.
+        // Round 1 polled the mailbox FIRST, in wave 0: that wave, always the last to finish its statistics,
+        // delayed the AGG of cur by its wait for the INC of prev -- a latency loop that cost 40-60 % of every
+        // workgroup's time (profiles/r02e diag).  Now wave 0 reduces cur first, polls, and only then issues its
+        // prefetch (consumed at the top of its next step); the other waves prefetch first as before.
+#if DBDE_POLL == 0
+        mailbox();
+        load_chunk<IN_MODE>(p, nxt, na, nb);
+        statistics();
+#elif DBDE_POLL == 1
+        load_chunk<IN_MODE>(p, nxt, na, nb);
+        statistics();
+        mailbox();
+#else
+        if (wave == 0) {
+            statistics();
+            mailbox();
+            load_chunk<IN_MODE>(p, nxt, na, nb);
+        } else {
+            load_chunk<IN_MODE>(p, nxt, na, nb);
+            statistics();
         }
+#endif
+#ifdef DBDE_DIAG
+        const uint64_t dg_b0 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();   // ---- 4. the one workgroup barrier ----
+#ifdef DBDE_DIAG
+        dg_bar += __builtin_amdgcn_s_memtime() - dg_b0;
+#endif
         const uint32_t inf = sh.lb[par][0], glob = sh.lb[par][1];
         // wave-uniform on purpose: a divergent exit test makes the compiler route every loop exit through one
         // flag-guarded block that also falls back into the loop header; that fake edge made it treat the
@@ -652,7 +725,15 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         }
 
         // ---- 5. prev: LDS -> global; cur: pack over it (wave-private region) -----------------------
-        if (prev.valid) store_wave_part<ALIGNED_OUT>(p, prev, prev_meta, prev_wbase, prev_wtot, inf, glob, pay, lane);
+        if (prev.valid) {
+            store_wave_part<ALIGNED_OUT>(p, prev, prev_meta, prev_wbase, prev_wtot, inf, glob, pay, lane);
+            // what depends only on prefixes -- frame header, the I32 fields, per-frame offset and size -- is
+            // written by the workgroup that holds the frame's first / last chunk (one lane, a few stores).  The
+            // scanner used to do this; with 64 or fewer chunks per frame it then met a frame boundary in every
+            // window of records and its rounds took twice as long (profiles/r02 diag).
+            if (tid == 64 * (kEncWaves - 1) && (prev.cf == 0u || prev.cf == p.chunks_per_frame - 1u))
+                write_frame_fields<ALIGNED_OUT>(p, prev.f, prev.cf, inf + prev_total, glob - inf);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (wtot != 0u) {
@@ -682,6 +763,17 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         step(0u, r0a, r0b, r1a, r1b);
         step(1u, r1a, r1b, r0a, r0b);
     } while (cur.valid || prev.valid);
+#ifdef DBDE_DIAG
+    if (tid == 0) {
+        atomicAdd(&p.diag[0], dg_wait);
+        atomicAdd(&p.diag[1], dg_nwait);
+        atomicAdd(&p.diag[2], __builtin_amdgcn_s_memtime() - dg_k0);
+        atomicAdd(&p.diag[7], dg_bar);
+        atomicAdd(&p.diag[8], 1ull);
+        atomicAdd(&p.diag[9], dg_npoll);
+        atomicAdd(&p.diag[10], dg_first);
+    }
+#endif
 }
 
 static int in_mode_of(const EncParams &p, bool fast_in) { return fast_in ? kInFast : (p.W >= 8 ? kInRaw : kInBytes); }

@@ -97,6 +97,18 @@ int main(int argc, char **argv) {
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ms[3] = 0; n[3] = 0;
     dbde_hip_timing_read(c, ms, n, 1);
+    if (getenv("ABBENCH_DIAG")) {   // -DDBDE_DIAG builds: in-kernel cycle counters of the encoder (sums over the timed steps)
+        using fn_diag = int (*)(ctx *, uint64_t *);
+        fn_diag dr = (fn_diag)dlsym(h, "dbde_hip_diag_read");
+        uint64_t d[16] = {0};
+        if (dr && dr(c, d) == 0 && d[8]) {
+            const double wg = (double)d[8];   // workgroup runs summed over steps
+            fprintf(stderr, "diag[%s %s]: per workgroup-run: kernel %.0f cyc, wait_inc %.0f cyc (%.1f %%, %.1f waits, %.2f polls each, %.0f %% answered at the first poll), wave0 at barrier %.0f cyc (%.1f %%) | "
+                    "scanner per launch: %.0f rounds, %.1f %% idle, %.1f records/round, %.0f cyc\n", tag, content,
+                    d[2] / wg, d[0] / wg, 100.0 * d[0] / d[2], d[1] / wg, (double)d[9] / (d[1] ? d[1] : 1), 100.0 * d[10] / (d[1] ? d[1] : 1), d[7] / wg, 100.0 * d[7] / d[2],
+                    (double)d[3] / steps, 100.0 * d[4] / (d[3] ? d[3] : 1), (double)d[6] / (d[3] ? d[3] : 1), (double)d[5] / steps);
+        }
+    }
     const double alg = (double)px * B + packed;
     const double enc = ms[0] / (n[0] ? n[0] : 1), idx = ms[1] / (n[1] ? n[1] : 1), dec = ms[2] / (n[2] ? n[2] : 1);
     printf("{\"tag\": \"%s\", \"W\": %d, \"H\": %d, \"frames\": %d, \"content\": \"%s\", \"layout\": \"%s\", \"steps\": %d, "

@@ -71,9 +71,41 @@ __global__ __launch_bounds__(256) void cp(const uint8_t *src, uint8_t *dst) {
     }
 }
 
+// Generic geometry (BASELINE configs[3], 1921x1081: every image row starts at an odd address): the decoder's
+// launch shape again (256 threads, 512 consecutive tiles, two per lane), bytes addressed as the codec does.
+//   MODE 0: two unaligned 8-byte accesses per image row and lane (one per tile)   <- round-1 kernels
+//   MODE 1: one unaligned 16-byte access per row and lane (both tiles when they are neighbours)
+//   MODE 2: the same on a 1920-wide, 16-byte aligned image (what alignment alone is worth)
+template <int MODE, bool WRITE>
+__global__ __launch_bounds__(256) void generic(uint8_t *img, int W, int H, uint32_t w, uint32_t T, uint32_t cpf, uint32_t *sink) {
+    const uint32_t f = blockIdx.x / cpf, cf = blockIdx.x - f * cpf;
+    uint8_t *base = img + (size_t)f * (size_t)W * (size_t)H;
+    const uint32_t t0 = cf * 512u + 2u * threadIdx.x;
+    if (t0 >= T) return;
+    const uint32_t ty = t0 / w, tx = t0 - ty * w;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int yy = 8 * (int)ty + r;
+        yy = yy < H ? yy : H - 1;
+        size_t x0 = 8u * tx;
+        if (x0 + 16 > (size_t)W) x0 = (size_t)W - 16;      // stay inside the row (edge fix-up is ALU work)
+        uint8_t *p = base + (size_t)yy * (size_t)W + x0;
+        if (MODE == 0) {
+            if (WRITE) { uint64_t v = t0; __builtin_memcpy(p, &v, 8); __builtin_memcpy(p + 8, &v, 8); }
+            else { uint64_t a, b; __builtin_memcpy(&a, p, 8); __builtin_memcpy(&b, p + 8, 8); acc ^= (uint32_t)(a ^ b) ^ (uint32_t)((a ^ b) >> 32); }
+        } else {
+            if (WRITE) { u32x4 v = {t0, t0, t0, t0}; __builtin_memcpy(p, &v, 16); }
+            else { u32x4 v; __builtin_memcpy(&v, p, 16); acc ^= v[0] ^ v[1] ^ v[2] ^ v[3]; }
+        }
+    }
+    if (!WRITE && acc == 0x12345u) sink[0] = acc;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
-int main() {
+int main(int argc, char **argv) {
+    const bool full = argc > 1;   // any argument: also the aligned fill/rows/wrows patterns
     const size_t bytes = 12ull << 30;
     const unsigned blocks = (unsigned)(bytes / 32768);
     uint8_t *a, *b;
@@ -96,8 +128,27 @@ int main() {
 #define W(P, N) timeit(N ? "write pat" #P " nt" : "write pat" #P " plain", [&] { hipLaunchKernelGGL((wr<P, N>), dim3(blocks), dim3(256), 0, 0, a, 7u); }, (double)bytes)
 #define R(P, N) timeit(N ? "read  pat" #P " nt" : "read  pat" #P " plain", [&] { hipLaunchKernelGGL((rd<P, N>), dim3(blocks), dim3(256), 0, 0, a, sink); }, (double)bytes)
 #define C(P, N) timeit(N ? "copy  pat" #P " nt" : "copy  pat" #P " plain", [&] { hipLaunchKernelGGL((cp<P, N>), dim3(blocks), dim3(256), 0, 0, a, b); }, 2.0 * bytes)
+    if (full) {
     W(0, false); W(0, true); W(1, false); W(1, true); W(2, false); W(2, true);
     R(0, false); R(0, true); R(1, false); R(1, true); R(2, false); R(2, true);
     C(0, false); C(0, true); C(1, false); C(1, true); C(2, false); C(2, true);
+    }
+    const int widths[] = {1921, 1922, 1924, 1928, 1936, 1920};
+    for (int W : widths) {
+        const int H = 1081;
+        const uint32_t w = (W + 7) / 8, h = (H + 7) / 8, T = w * h, cpf = (T + 511) / 512;
+        const int frames = (int)(bytes / ((size_t)W * H)) - 1;
+        const double moved = (double)frames * W * H;
+        const unsigned gb = (unsigned)frames * cpf;
+        char name[64];
+        snprintf(name, sizeof name, "W=%d read  2x8B", W);
+        timeit(name, [&] { hipLaunchKernelGGL((generic<0, false>), dim3(gb), dim3(256), 0, 0, a, W, H, w, T, cpf, sink); }, moved);
+        snprintf(name, sizeof name, "W=%d read  1x16B", W);
+        timeit(name, [&] { hipLaunchKernelGGL((generic<1, false>), dim3(gb), dim3(256), 0, 0, a, W, H, w, T, cpf, sink); }, moved);
+        snprintf(name, sizeof name, "W=%d write 2x8B", W);
+        timeit(name, [&] { hipLaunchKernelGGL((generic<0, true>), dim3(gb), dim3(256), 0, 0, a, W, H, w, T, cpf, sink); }, moved);
+        snprintf(name, sizeof name, "W=%d write 1x16B", W);
+        timeit(name, [&] { hipLaunchKernelGGL((generic<1, true>), dim3(gb), dim3(256), 0, 0, a, W, H, w, T, cpf, sink); }, moved);
+    }
     return 0;
 }

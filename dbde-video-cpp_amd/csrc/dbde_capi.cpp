@@ -26,7 +26,7 @@ struct TimedSpan {
 };
 
 struct Geometry {
-    uint32_t w, h, T, cpf;
+    uint32_t w, h, T;
     uint64_t pixels;
 };
 
@@ -93,7 +93,6 @@ bool geometry(int W, int H, Geometry &g) {
     g.w = (uint32_t)w;
     g.h = (uint32_t)h;
     g.T = (uint32_t)T;
-    g.cpf = (uint32_t)((T + kChunkTiles - 1) / kChunkTiles);
     g.pixels = (uint64_t)W * (uint64_t)H;
     return true;
 }
@@ -307,7 +306,22 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
         return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
-    const uint32_t dcpf = g.cpf;   // chunks of kChunkTiles tiles, one decode workgroup each
+    // How the pixels reach the image (decode_kernel<IMG>): direct register -> image stores are only FAST when a
+    // wave's 1 KB covers whole cache lines (W, the frame size and the base multiples of 128); widths that keep
+    // tile rows 8-byte aligned are staged in LDS and leave as whole cache lines of the chunk's byte range; odd
+    // widths store tile by tile.
+    const uintptr_t ib = reinterpret_cast<uintptr_t>(d_images);
+    int img_mode = 2;
+    if (W % 128 == 0 && g.pixels % 128 == 0 && (ib & 127u) == 0) img_mode = 0;
+    else if (W % 8 == 0 && (ib & 7u) == 0 && g.w <= kChunkTiles) img_mode = 1;
+#ifdef DBDE_FORCE_GENERIC
+    img_mode = 2;
+#endif
+#ifdef DBDE_FORCE_LINEAR
+    img_mode = 1;
+#endif
+    const DecGeom dg = dec_geometry(g.w, g.h, img_mode == 1);
+    const uint32_t dcpf = dg.cpf;   // whole tile rows (or pieces of a wide one) per chunk, one decode workgroup each
     if (dcpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
     const uint64_t n_chunks64 = (uint64_t)n_frames * dcpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
@@ -326,7 +340,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     ip.results = d_results;
     ip.T = g.T;
     ip.chunks_per_frame = dcpf;
-    ip.chunk_shift = kChunkShift;
+    ip.geom = dg;
     // Few frames: cut each frame into pieces so that the index pass fills the device too
     // (>= 4 chunks per piece, about 1024 workgroups in all); from 256 frames on, one workgroup per frame.
     ip.split = 1;
@@ -366,12 +380,9 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.T = g.T;
     p.chunks_per_frame = dcpf;
     p.n_chunks = (uint32_t)n_chunks64;
-    bool fast_img = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
-#ifdef DBDE_FORCE_GENERIC
-    fast_img = false;
-#endif
+    p.geom = dg;
     span_begin(ctx, 2);
-    HIP_TRY(ctx, launch_decode(p, fast_img, ctx->stream));
+    HIP_TRY(ctx, launch_decode(p, img_mode, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;
 }

@@ -7,12 +7,52 @@ namespace dbde {
 
 // A chunk is the unit of one 256-thread workgroup: 512 consecutive tiles in stream order
 // (row-major over the frame's tiles), two tiles per lane.
-#ifndef DBDE_DEC_CT
-#define DBDE_DEC_CT 512   // compile-time only (A/B builds in profiles/variants.sh); the shipped library is 512
-#endif
-constexpr uint32_t kChunkTiles = DBDE_DEC_CT;
-constexpr uint32_t kChunkShift = kChunkTiles == 256 ? 8 : (kChunkTiles == 1024 ? 10 : 9);
-static_assert((1u << kChunkShift) == kChunkTiles, "decode chunk must be 256, 512 or 1024 tiles");
+// Capacity of one decode workgroup: 256 threads, two tiles per lane.
+constexpr uint32_t kChunkTiles = 512;
+
+// Chunk geometry of the DECODER.  A chunk is the unit of one workgroup and always lines up with the image:
+//   * row-aligned form, w <= 512 tiles across: a chunk is a run of WHOLE tile rows (rows * w <= 512 tiles) --
+//     its 8 * rows image rows are then ONE contiguous byte range of the frame (the staged-image decode path);
+//   * row-aligned form, wider frames: a chunk is one piece (<= 512 tiles) of a tile row;
+//   * plain form: 512 consecutive tiles, wherever they fall.
+// Chunks partition the frame's tiles in stream order (row-major), so a chunk's payload is one contiguous
+// byte range of the stream as well.  (The north star's "one wavefront per tile-row strip".)
+struct DecGeom {
+    uint32_t w, h, T;
+    uint32_t ct;        // whole-row form: tiles per chunk (rows * w); piece form: 512
+    uint32_t pieces;    // chunks per tile row; 1 = whole-row form
+    uint32_t cpf;       // chunks per frame
+};
+// row_aligned = false: plain runs of 512 consecutive tiles (a workgroup's time is nearly independent of how
+// many of its 512 tile slots are used, so full chunks win wherever alignment with the image buys nothing).
+__host__ __device__ inline DecGeom dec_geometry(uint32_t w, uint32_t h, bool row_aligned) {
+    DecGeom g;
+    g.w = w; g.h = h; g.T = w * h;
+    if (!row_aligned) {
+        g.ct = kChunkTiles; g.pieces = 1u; g.cpf = (g.T + kChunkTiles - 1u) / kChunkTiles;
+    } else if (w <= kChunkTiles) {
+        uint32_t rows = kChunkTiles / w;   // the staged image, 8 * rows * W <= 64 * rows * w bytes, fits 32 KiB
+        if (rows < 1u) rows = 1u;
+        g.ct = rows * w; g.pieces = 1u; g.cpf = (h + rows - 1u) / rows;
+    } else {
+        g.ct = kChunkTiles; g.pieces = (w + kChunkTiles - 1u) / kChunkTiles; g.cpf = h * g.pieces;
+    }
+    return g;
+}
+// First tile (stream order) of chunk c; c == cpf gives T.
+__host__ __device__ inline uint32_t dec_chunk_begin(const DecGeom &g, uint32_t c) {
+    if (g.pieces == 1u) { const uint64_t b = (uint64_t)c * g.ct; return b < g.T ? (uint32_t)b : g.T; }
+    if (c >= g.cpf) return g.T;
+    const uint32_t ty = c / g.pieces, pc = c - ty * g.pieces;
+    return ty * g.w + pc * kChunkTiles;
+}
+// Chunk that holds tile `pos` (pos < T).
+__host__ __device__ inline uint32_t dec_chunk_of(const DecGeom &g, uint32_t pos) {
+    if (g.pieces == 1u) return pos / g.ct;
+    const uint32_t ty = pos / g.w, tx = pos - ty * g.w;
+    return ty * g.pieces + tx / kChunkTiles;
+}
+
 // The encoder walks larger chunks (fewer ticket draws): one 512-thread workgroup per 1024 tiles.
 constexpr uint32_t kEncChunkTiles = 1024;
 
@@ -56,6 +96,7 @@ struct DecParams {
     int W, H;
     uint32_t w, h, T;
     uint32_t chunks_per_frame, n_chunks;
+    DecGeom geom;
 };
 
 struct IdxParams {
@@ -66,7 +107,7 @@ struct IdxParams {
     uint32_t *frame_ok;             // out [n_frames]
     void *results;                  // optional dbde_hip_frame_result[n_frames]
     uint32_t T, chunks_per_frame;
-    uint32_t chunk_shift;           // log2(tiles per chunk)
+    DecGeom geom;                   // which tiles a chunk holds
     uint32_t split;                 // workgroups per frame (1 = decode_index_kernel, >1 = the split form)
     uint32_t *frame_ctr;            // [n_frames] arrivals per frame, zero between launches (split form)
     uint32_t *frame_flag;           // [n_frames] bit0 = a depth byte > 8 was seen (split form)
@@ -83,7 +124,8 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
-hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s);
+// img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
+hipError_t launch_decode(const DecParams &p, int img_mode, hipStream_t s);
 hipError_t launch_synth(int mode, uint64_t seed, uint64_t first_frame, int n_frames, int W, int H,
                         uint8_t *d_images, hipStream_t s);
 // Serial frame-to-frame hop over a concatenated stream (one wave); see dbde_hip_index_stream.

@@ -831,6 +831,12 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
         const uint32_t head = (uint32_t)(reinterpret_cast<uintptr_t>(darr) & 15u);   // bytes before the array in piece 0
         const uint8_t *a_lo = darr - head;                                          // 16-byte aligned
         const uint32_t npieces = (head + T + 15u) >> 4;
+        // chunk of a piece's first tile, kept incrementally (whole-row form with >= 16 tiles per chunk: a piece
+        // then meets at most one chunk boundary); everything else divides
+        const bool incr = p.geom.pieces == 1u && p.geom.ct >= 16u;
+        const uint32_t step = 16u * blockDim.x, q_step = incr ? step / p.geom.ct : 0u, r_step = incr ? step - q_step * p.geom.ct : 0u;
+        uint32_t k_run = 0, rem_run = 0;
+        bool have_run = false;
         for (uint32_t i = tid; i < npieces; i += blockDim.x) {
             uint4 q;
             if (a_lo + 16ull * (i + 1u) <= p.stream + p.stream_bytes) {
@@ -843,42 +849,56 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
                 }
                 q = make_uint4(wq[0], wq[1], wq[2], wq[3]);
             }
-            const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
-            // position of this piece's byte 0 relative to the array start
+            uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+            // tile positions this piece covers: [lo, hi) inside [0, T)
             const long long pos0 = 16ll * i - (long long)head;
-            uint32_t sum_lo = 0, sum_hi = 0;
-            const uint32_t k_lo = (uint32_t)((pos0 < 0 ? 0 : pos0) >> p.chunk_shift);
+            const uint32_t lo = pos0 < 0 ? 0u : (uint32_t)pos0;
+            const uint32_t hi = pos0 + 16 > (long long)T ? T : (uint32_t)(pos0 + 16);
+            // keep only the bytes inside [lo, hi)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t x = wv[j];
                 const long long pj = pos0 + 4 * j;
-                // keep only bytes with 0 <= position < T
                 uint32_t mask = 0xFFFFFFFFu;
                 if (pj < 0) mask = (pj <= -4) ? 0u : (0xFFFFFFFFu << (8 * (int)(-pj)));
                 if (pj + 4 > (long long)T) {
                     const long long keep = (long long)T - pj;   // bytes to keep
                     mask &= keep <= 0 ? 0u : (keep >= 4 ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (int)(4 - keep))));
                 }
-                x &= mask;
-                bad_depth |= (x & 0xF0F0F0F0u) | ((x + 0x77777777u) & 0x80808080u);   // any byte > 8
-                // a dword belongs to one chunk unless it straddles a 512-byte boundary of the array
-                const long long pc = pj < 0 ? 0 : pj;
-                const uint32_t kj = (uint32_t)(pc >> p.chunk_shift);
-                const uint32_t kend = (uint32_t)((pj + 3 < 0 ? 0 : pj + 3) >> p.chunk_shift);
-                if (kj == kend) {
-                    const uint32_t sb = __builtin_amdgcn_sad_u8(x, 0u, 0u);
-                    if (kj == k_lo) sum_lo += sb; else sum_hi += sb;
-                } else {   // split the dword at the boundary byte by byte
+                wv[j] &= mask;
+                bad_depth |= (wv[j] & 0xF0F0F0F0u) | ((wv[j] + 0x77777777u) & 0x80808080u);   // any byte > 8
+            }
+            uint32_t k_first, k_last;
+            if (incr && pos0 >= 0) {
+                if (!have_run) { k_run = lo / p.geom.ct; rem_run = lo - k_run * p.geom.ct; have_run = true; }
+                k_first = k_run;
+                k_last = rem_run + (hi - 1u - lo) >= p.geom.ct ? k_run + 1u : k_run;
+                k_run += q_step; rem_run += r_step;
+                if (rem_run >= p.geom.ct) { rem_run -= p.geom.ct; k_run++; }
+            } else {
+                k_first = dec_chunk_of(p.geom, lo);
+                k_last = dec_chunk_of(p.geom, hi - 1u);
+            }
+            if (k_first == k_last || (incr && pos0 >= 0)) {
+                // one chunk, or (every 32nd piece when the array sits 8 mod 16) ONE boundary inside the piece:
+                // bytes below the boundary tile go to k_first, the rest to the next chunk -- no branches
+                const long long bnd = k_first == k_last ? (long long)T : (long long)(k_first + 1u) * p.geom.ct;
+                uint32_t sum_lo = 0, sum_hi = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const long long pb = pj + b;
-                        const uint32_t v = (x >> (8 * b)) & 0xFFu;
-                        if (pb >= 0) { if ((uint32_t)(pb >> p.chunk_shift) == k_lo) sum_lo += v; else sum_hi += v; }
-                    }
+                for (int j = 0; j < 4; j++) {
+                    const long long nb = bnd - (pos0 + 4 * j);   // bytes of dword j below the boundary
+                    const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (int)(4 - nb))));
+                    sum_lo += __builtin_amdgcn_sad_u8(wv[j] & m, 0u, 0u);
+                    sum_hi += __builtin_amdgcn_sad_u8(wv[j] & ~m, 0u, 0u);
+                }
+                if (sum_lo) atomicAdd(&s_sum[k_first], sum_lo);
+                if (sum_hi) atomicAdd(&s_sum[k_first + 1u], sum_hi);
+            } else {                   // several boundaries possible (tiny chunks, wide frames in pieces): byte by byte
+                for (uint32_t pos = lo; pos < hi; pos++) {
+                    const uint32_t b = (uint32_t)((long long)pos - pos0);
+                    const uint32_t v = (wv[b >> 2] >> (8u * (b & 3u))) & 0xFFu;
+                    if (v) atomicAdd(&s_sum[dec_chunk_of(p.geom, pos)], v);
                 }
             }
-            if (sum_lo) atomicAdd(&s_sum[k_lo], sum_lo);
-            if (sum_hi && k_lo + 1u < cpf) atomicAdd(&s_sum[k_lo + 1u], sum_hi);
         }
     }
     if (bad_depth) atomicOr(&s_flags, 1u);
@@ -965,19 +985,20 @@ __global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
     // ---- chunk sums of this piece ----
     const uint32_t per = (cpf + p.split - 1u) / p.split;
     const uint32_t k_begin = piece * per, k_end = k_begin + per < cpf ? k_begin + per : cpf;
-    const uint32_t ct = 1u << p.chunk_shift, bpl = ct >> 6;   // bytes per lane: 4, 8 or 16
     uint32_t bad = 0;
     for (uint32_t k = k_begin + (uint32_t)wave; k < k_end; k += 4u) {
         uint32_t sum = 0;
         if (in_range) {
             const uint8_t *darr = fb + 24;
-            const uint32_t pos = k * ct + (uint32_t)lane * bpl;
-            for (uint32_t j = 0; j < bpl; j += 4u) {
-                const uint32_t q = pos + j;
-                if (q < T) {   // the 4 bytes at q lie inside the frame (the min array follows)
+            // the chunk's tiles [c_lo, c_hi): at most 512, eight depth bytes per lane
+            const uint32_t c_lo = dec_chunk_begin(p.geom, k), c_hi = dec_chunk_begin(p.geom, k + 1u);
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j += 4u) {
+                const uint32_t q = c_lo + (uint32_t)lane * 8u + j;
+                if (q < c_hi) {   // the 4 bytes at q lie inside the frame (the min array follows the depths)
                     uint32_t x;
                     __builtin_memcpy(&x, darr + q, 4);
-                    const uint32_t keep = T - q;   // tiles left
+                    const uint32_t keep = c_hi - q;   // tiles of this chunk left
                     if (keep < 4u) x &= 0xFFFFFFFFu >> (8u * (4u - keep));
                     bad |= (x & 0xF0F0F0F0u) | ((x + 0x77777777u) & 0x80808080u);   // any byte > 8
                     sum += __builtin_amdgcn_sad_u8(x, 0u, 0u);
@@ -1119,6 +1140,47 @@ __device__ __forceinline__ void unpack_tile_d8_from_lds(const uint8_t *s_img, ui
     }
 }
 
+// Workgroup -> chunk.  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD
+// b % 8), and each XCD has its own L2: with the identity mapping every XCD touches every
+// eighth 32 KB piece of the stream and of the image.  Here the launch is cut into groups of
+// 8 * kXcdRun chunks and, inside a group, XCD x takes kXcdRun CONSECUTIVE chunks (0.5 MB of
+// image, as much stream): measured 5-6 % faster on the full-size decode, flat for runs of
+// 8..256 chunks, slower below 8.  All XCDs still move through the buffers together.  A
+// trailing partial group keeps the identity mapping.
+constexpr uint32_t kXcdRun = 16;
+__device__ __forceinline__ uint32_t xcd_local_chunk(uint32_t b, uint32_t n_chunks) {
+    constexpr uint32_t kGroup = 8u * kXcdRun;
+    const uint32_t grp = b / kGroup, rem = b % kGroup;
+    if ((grp + 1u) * kGroup > n_chunks) return b;
+    return grp * kGroup + (rem & 7u) * kXcdRun + (rem >> 3);
+}
+
+// LDS image of a chunk's payload: up to 15 bytes of alignment shift + 64 B per tile + one qword
+// of over-read, rounded up to whole 256-byte swizzle groups.  The same memory later holds the chunk's
+// decoded pixels on the staged (kImgLinear) path: 8 * rows * pitch <= 32 KiB (dec_geometry) + slack.
+struct DecLds {
+    static constexpr int kThreads = kChunkTiles / 2;
+    static constexpr int kWaves = kChunkTiles / 128;
+    // (and, on the staged-image path, 8 image-row pieces of 4096 B each shifted by up to 127 B: 8 * 4224 + 128)
+    static constexpr uint32_t kSlots = 2128u;   // 34,048 B: four workgroups per CU
+    static constexpr int kPieces = (kSlots + kThreads - 1) / kThreads;   // 16-B pieces per thread
+};
+
+// The LDS of gfx950 takes 8- and 16-byte accesses at ANY byte address at the price of aligned ones
+// (profiles/lds_unaligned_probe.hip: every offset bit-exact, same time).  The compiler does not know that and
+// would split an under-aligned access into bytes, so the instruction is spelled out.
+__device__ __forceinline__ void lds_store_u64_any(uint8_t *s_base, uint32_t byte_addr, uint32_t lo, uint32_t hi) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_base + byte_addr;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+// Exactly n (1..7) bytes of v at any LDS byte address (the last, partial tile of an image row).
+__device__ __forceinline__ void lds_store_bytes(uint8_t *s_px, uint32_t a, uint64_t v, uint32_t n) {
+    if (n & 4u) { __builtin_memcpy(s_px + a, &v, 4); a += 4u; v >>= 32; }       // (byte stores: the compiler splits them)
+    if (n & 2u) { s_px[a] = (uint8_t)v; s_px[a + 1u] = (uint8_t)(v >> 8); a += 2u; v >>= 16; }
+    if (n & 1u) s_px[a] = (uint8_t)v;
+}
+
 // Write one (possibly partial) tile: only the valid region (dbde_util.cpp:281-289).
 __device__ __forceinline__ void store_tile_generic(uint8_t *img, int W, int H, uint32_t w, uint32_t t,
                                                    const uint32_t (&v)[16]) {
@@ -1142,33 +1204,26 @@ __device__ __forceinline__ void store_tile_generic(uint8_t *img, int W, int H, u
     }
 }
 
-// Workgroup -> chunk.  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD
-// b % 8), and each XCD has its own L2: with the identity mapping every XCD touches every
-// eighth 32 KB piece of the stream and of the image.  Here the launch is cut into groups of
-// 8 * kXcdRun chunks and, inside a group, XCD x takes kXcdRun CONSECUTIVE chunks (0.5 MB of
-// image, as much stream): measured 5-6 % faster on the full-size decode, flat for runs of
-// 8..256 chunks, slower below 8.  All XCDs still move through the buffers together.  A
-// trailing partial group keeps the identity mapping.
-constexpr uint32_t kXcdRun = 16;
-__device__ __forceinline__ uint32_t xcd_local_chunk(uint32_t b, uint32_t n_chunks) {
-    constexpr uint32_t kGroup = 8u * kXcdRun;
-    const uint32_t grp = b / kGroup, rem = b % kGroup;
-    if ((grp + 1u) * kGroup > n_chunks) return b;
-    return grp * kGroup + (rem & 7u) * kXcdRun + (rem >> 3);
-}
+// How decoded pixels reach the image.
+//   kImgDirect : W % 16 == 0 and a 16-byte aligned image: every lane's two tiles are one aligned 16-byte
+//                store per image row (whole cache lines per wave when W % 128 == 0).
+//   kImgLinear : any geometry.  Partial cache-line writes are what makes odd widths slow (unaligned 16-byte
+//                stores run at 3.2 TB/s against 5.6 aligned, profiles/mempattern.hip; per-lane alignment is
+//                not the issue), so the chunk's pixels are staged in LDS as they lie in the frame -- the
+//                chunk's contiguous byte range (whole tile rows: image rows follow each other at pitch W) or
+//                one range per image row (a piece of a frame wider than 4096) -- placed so that LDS and
+//                global addresses agree mod 16.  Tile rows go in with unaligned 8-byte LDS stores; the range
+//                leaves as aligned 16-byte blocks (ds_read_b128 -> global store, no arithmetic), with byte
+//                stores only in the first and last block of a range.  Only the valid region is ever written
+//                (dbde_util.cpp:281-289): the last tile of an image row stores its W % 8 valid bytes, rows
+//                >= H lie behind the copied range.  Used where the tile rows land 8-byte aligned in LDS
+//                (W % 8 == 0): 8-byte LDS stores at odd addresses took 5x the time of aligned ones here.
+//   kImgTiles  : everything else (odd widths): each tile row is one 8-byte store at its own address.
+constexpr int kImgDirect = 0, kImgLinear = 1, kImgTiles = 2;
 
-// LDS image of a chunk's payload: up to 15 bytes of alignment shift + 64 B per tile + one qword
-// of over-read, rounded up to whole 256-byte swizzle groups.
-template <int CT> struct DecGeom {
-    static constexpr int kThreads = CT / 2;
-    static constexpr int kWaves = CT / 128;
-    static constexpr uint32_t kSlots = ((15u + CT * 64u + 8u + 15u) / 16u + 15u) / 16u * 16u;
-    static constexpr int kPieces = (kSlots + kThreads - 1) / kThreads;   // 16-B pieces per thread
-};
-
-template <bool FAST_IMG, int CT>
-__global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
-    typedef DecGeom<CT> G;
+template <int IMG>
+__global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
+    typedef DecLds G;
     __shared__ __attribute__((aligned(16))) uint64_t s_in[G::kSlots * 2];
     __shared__ uint32_t s_wave_tot[G::kWaves];
 
@@ -1184,8 +1239,10 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
     if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
 
     const uint8_t *fb = p.stream + foff;
-    const uint32_t t0 = cf * (uint32_t)CT + 2u * (uint32_t)tid;
-    const bool hasA = t0 < p.T, hasB = t0 + 1u < p.T;
+    const uint32_t t_begin = dec_chunk_begin(p.geom, cf);
+    const uint32_t n_tiles = dec_chunk_begin(p.geom, cf + 1u) - t_begin;   // <= 512
+    const uint32_t t0 = t_begin + 2u * (uint32_t)tid;
+    const bool hasA = 2u * (uint32_t)tid < n_tiles, hasB = 2u * (uint32_t)tid + 1u < n_tiles;
     const uint8_t *depth_arr = fb + 24;
     const uint8_t *min_arr = fb + 28 + p.T;
 
@@ -1221,8 +1278,8 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
         reinterpret_cast<uint8_t *>(s_in)[16u * swz16(n16_dma) + (uint32_t)tid] = b < s_end ? *b : (uint8_t)0;
     }
     uint32_t dA = 0, dB = 0, mA = 0, mB = 0;
-    // t0 is even: when both byte arrays start at even addresses the lane's two tiles are one u16 each
-    if (hasB && ((reinterpret_cast<uintptr_t>(depth_arr) | reinterpret_cast<uintptr_t>(min_arr)) & 1u) == 0u) {
+    // the lane's two tiles are one u16 load per array where that address is even
+    if (hasB && ((reinterpret_cast<uintptr_t>(depth_arr + t0) | reinterpret_cast<uintptr_t>(min_arr + t0)) & 1u) == 0u) {
         const uint32_t d2 = *reinterpret_cast<const uint16_t *>(depth_arr + t0);
         const uint32_t m2 = *reinterpret_cast<const uint16_t *>(min_arr + t0);
         dA = d2 & 0xFFu; dB = d2 >> 8; mA = m2 & 0xFFu; mB = m2 >> 8;
@@ -1257,36 +1314,119 @@ __global__ __launch_bounds__(CT / 2) void decode_kernel(DecParams p) {
     }
 
     uint8_t *img = p.images + (size_t)f * p.frame_pixels;
-    if (FAST_IMG) {
-        if (hasA) {
+    if (IMG == kImgDirect) {
+        if (hasA) {   // W % 16 == 0: w is even and t_begin a multiple of w (or of 512), so both tiles share a tile row
             const uint32_t ty = t0 / p.w, tx = t0 - ty * p.w;
             uint8_t *base = img + (size_t)(8u * tx);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int yy = 8 * (int)ty + r;
                 if (yy < p.H) {
-                    uint4 q;
-                    q.x = va[2 * r]; q.y = va[2 * r + 1]; q.z = vb[2 * r]; q.w = vb[2 * r + 1];
-                    if (DBDE_NT) {
-                        u32x4_t o;
-                        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
-                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W));
-                    } else {
-                        *reinterpret_cast<uint4 *>(base + (size_t)yy * (size_t)p.W) = q;
-                    }
+                    u32x4_t o;
+                    o[0] = va[2 * r]; o[1] = va[2 * r + 1]; o[2] = vb[2 * r]; o[3] = vb[2 * r + 1];
+                    if (DBDE_NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W));
+                    else *reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W) = o;
                 }
             }
         }
-    } else {
+        return;
+    }
+
+    if (IMG == kImgTiles) {   // any geometry, tile by tile: 8-byte stores at the tile's own (arbitrary) address
         if (hasA) store_tile_generic(img, p.W, p.H, p.w, t0, va);
         if (hasB) store_tile_generic(img, p.W, p.H, p.w, t0 + 1u, vb);
+        return;
+    }
+
+    // ---- kImgLinear: stage the pixels in LDS as they lie in the frame, leave as whole cache lines ----------
+    const bool whole_rows = p.geom.pieces == 1u;
+    const uint32_t ty0 = whole_rows ? t_begin / p.w : cf / p.geom.pieces;
+    const uint32_t tx0 = whole_rows ? 0u : (cf - ty0 * p.geom.pieces) * kChunkTiles;
+    const uint32_t wspan = whole_rows ? p.w : n_tiles;                     // tiles across in the staged image
+    const uint32_t Wu = (uint32_t)p.W, y0 = 8u * ty0;
+    const uint32_t tile_rows = whole_rows ? n_tiles / p.w : 1u;
+    const uint32_t y_end = y0 + 8u * tile_rows < (uint32_t)p.H ? y0 + 8u * tile_rows : (uint32_t)p.H;
+    const uint32_t x_valid = Wu - 8u * tx0 < 8u * wspan ? Wu - 8u * tx0 : 8u * wspan;   // valid bytes of one image row here
+    // whole-row form: ONE range, image rows at pitch W; piece form: a range per image row, LDS pitch 4224
+    uint8_t *g_first = img + (size_t)y0 * (size_t)p.W + (size_t)(8u * tx0);
+    const uint32_t l_pitch = whole_rows ? Wu : 8u * kChunkTiles + 128u;
+    // LDS byte address of image row ry (relative to y0), column byte xb:
+    //   whole rows: g7 + ry * W + xb                 (one range: LDS and global agree mod 128 throughout)
+    //   pieces    : ((g7 + ry * W) & 127) + ry * l_pitch + xb   (each image row is its own range)
+    // mod 128, not 16: a wave's 64 x 16 B must cover whole cache lines (a 4-lane group one 64-byte sector),
+    // or the stores run at little more than half rate however well each lane is aligned (profiles/mempattern.hip)
+    const uint32_t g7 = (uint32_t)(reinterpret_cast<uintptr_t>(g_first) & 127u);
+    uint8_t *s_px = reinterpret_cast<uint8_t *>(s_in);
+    __syncthreads();   // every wave has finished reading the payload image: the memory changes hands
+    {
+        const uint32_t iA = 2u * (uint32_t)tid;
+        const uint32_t rowA = iA / wspan, colA = iA - rowA * wspan;
+        const uint32_t rowB = colA + 1u == wspan ? rowA + 1u : rowA, colB = colA + 1u == wspan ? 0u : colA + 1u;
+        // bytes of the tile's rows that exist in the image (8, or W % 8 for the last tile of an image row)
+        const uint32_t nA = 8u * colA + 8u <= x_valid ? 8u : x_valid - 8u * colA;
+        const uint32_t nB = 8u * colB + 8u <= x_valid ? 8u : x_valid - 8u * colB;
+        const uint32_t aA = whole_rows ? g7 + 8u * rowA * Wu + 8u * colA : 8u * colA;   // the tile's row 0, less the row term
+        const uint32_t aB = whole_rows ? g7 + 8u * rowB * Wu + 8u * colB : 8u * colB;
+        auto row_term = [&](uint32_t r) -> uint32_t {   // wave-uniform
+            return whole_rows ? r * Wu : ((g7 + r * Wu) & 127u) + r * l_pitch;
+        };
+        const bool all_rows = y0 + 8u * tile_rows <= (uint32_t)p.H;
+        if (all_rows && __all((int)((!hasA || nA == 8u) && (!hasB || nB == 8u)))) {   // no edge in this wave: straight stores
+            if (hasA) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aA + row_term((uint32_t)r), va[2 * r], va[2 * r + 1]);
+            }
+            if (hasB) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aB + row_term((uint32_t)r), vb[2 * r], vb[2 * r + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t rt = row_term((uint32_t)r);
+                if (hasA && y0 + 8u * rowA + (uint32_t)r < y_end) {
+                    if (nA == 8u) lds_store_u64_any(s_px, aA + rt, va[2 * r], va[2 * r + 1]);
+                    else lds_store_bytes(s_px, aA + rt, ((uint64_t)va[2 * r + 1] << 32) | va[2 * r], nA);
+                }
+                if (hasB && y0 + 8u * rowB + (uint32_t)r < y_end) {
+                    if (nB == 8u) lds_store_u64_any(s_px, aB + rt, vb[2 * r], vb[2 * r + 1]);
+                    else lds_store_bytes(s_px, aB + rt, ((uint64_t)vb[2 * r + 1] << 32) | vb[2 * r], nB);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm stores are invisible to the compiler's counters
+    __syncthreads();
+    const uint32_t n_ranges = whole_rows ? 1u : y_end - y0;
+    for (uint32_t s = 0; s < n_ranges; s++) {
+        uint8_t *g0 = g_first + (size_t)s * Wu;
+        const uint32_t bytes = whole_rows ? (y_end - y0) * Wu : x_valid;
+        const uint32_t head = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 127u);
+        uint8_t *a0 = g0 - head;                                             // cache-line aligned
+        const uint8_t *l0 = s_px + (whole_rows ? 0u : s * l_pitch);          // LDS byte of global byte a0
+        const uint32_t n_blocks = (head + bytes + 15u) >> 4;
+        for (uint32_t j = (uint32_t)tid; j < n_blocks; j += (uint32_t)G::kThreads) {
+            if (16u * j + 16u <= head || 16u * j >= head + bytes) continue;   // (blocks of the first line before the range)
+            if (16u * j >= head && 16u * j + 16u <= head + bytes) {
+                const u32x4_t q = *reinterpret_cast<const u32x4_t *>(l0 + 16u * j);
+                if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(a0 + 16ull * j));
+                else *reinterpret_cast<u32x4_t *>(a0 + 16ull * j) = q;
+            } else {       // first / last block of the range: only the bytes that belong to it
+#pragma unroll
+                for (uint32_t b = 0; b < 16u; b++) {
+                    const uint32_t o = 16u * j + b;
+                    if (o >= head && o < head + bytes) a0[o] = l0[o];
+                }
+            }
+        }
     }
 }
 
-hipError_t launch_decode(const DecParams &p, bool fast_img, hipStream_t s) {
+hipError_t launch_decode(const DecParams &p, int img_mode, hipStream_t s) {
     dim3 grid(p.n_chunks), block(kChunkTiles / 2);
-    if (fast_img) hipLaunchKernelGGL((decode_kernel<true, (int)kChunkTiles>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((decode_kernel<false, (int)kChunkTiles>), grid, block, 0, s, p);
+    if (img_mode == kImgDirect) hipLaunchKernelGGL((decode_kernel<kImgDirect>), grid, block, 0, s, p);
+    else if (img_mode == kImgLinear) hipLaunchKernelGGL((decode_kernel<kImgLinear>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((decode_kernel<kImgTiles>), grid, block, 0, s, p);
     return hipGetLastError();
 }
 

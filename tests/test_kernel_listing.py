@@ -102,5 +102,5 @@ def test_no_scratch_and_expected_occupancy(listing):
                              "lds": int(get("group_segment_fixed_size"))}
     enc = meta["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE"]
     assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, enc
-    dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILb1E")]
+    dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi")]
     assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 64 for d in dec), dec

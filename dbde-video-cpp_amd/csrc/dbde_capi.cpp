@@ -237,7 +237,17 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
     const uint64_t maxf = 32ull + 66ull * g.T;
-    const uint32_t enc_cpf = (g.T + kEncChunkTiles - 1) / kEncChunkTiles;
+    bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
+#ifdef DBDE_FORCE_GENERIC   // A/B builds only: the any-geometry kernels on aligned images
+    fast_in = false;
+#endif
+    // chunk geometry of the encoder (EncParams): plain runs of 1024 tiles, or -- any-geometry path, W >= 16 --
+    // 512 tile PAIRS that never leave a tile row
+    uint32_t enc_cpf = (g.T + kEncChunkTiles - 1) / kEncChunkTiles, lanes_per_row = 0;
+    if (!fast_in && W >= 16) {
+        lanes_per_row = (g.w + 1u) / 2u;
+        enc_cpf = (uint32_t)(((uint64_t)g.h * lanes_per_row + kEncChunkTiles / 2u - 1u) / (kEncChunkTiles / 2u));
+    }
     const uint64_t n_chunks64 = (uint64_t)n_frames * enc_cpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: too many chunks in one call");
     if (slot_stride) {
@@ -281,14 +291,11 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.h = g.h;
     p.T = g.T;
     p.chunks_per_frame = enc_cpf;
+    p.lanes_per_row = lanes_per_row;
     p.n_chunks = n_chunks;
     p.flags = ctx->exp_flags;
     p.grid_blocks = ctx->enc_grid;
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
-    bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
-#ifdef DBDE_FORCE_GENERIC   // A/B builds only: the any-geometry kernels on aligned images
-    fast_in = false;
-#endif
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);
     HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));

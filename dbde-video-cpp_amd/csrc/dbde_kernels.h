@@ -80,6 +80,10 @@ struct EncParams {
     int W, H;
     uint32_t w, h, T;              // tiles across, down, total
     uint32_t chunks_per_frame, n_chunks;
+    // Any-geometry input path: lanes_per_row = ceil(w / 2) != 0 -> lanes are dealt to tile PAIRS that never leave a
+    // tile row (the last lane of a row holds one tile when w is odd); a chunk is 512 consecutive pairs in stream
+    // order, wherever they fall.  lanes_per_row == 0: plain runs of 1024 tiles (w even: pairs never straddle).
+    uint32_t lanes_per_row;
     uint32_t flags;                // bit 0: force ticket mode (A/B measurements)
     uint32_t grid_blocks;          // resident workgroups of the persistent encoder
     unsigned long long *diag;      // [16] cycle counters, written only by -DDBDE_DIAG builds (profiles/variants.sh)

@@ -345,7 +345,8 @@ struct EncShared {
 };
 
 struct ChunkRef {
-    uint32_t c, f, cf, t0;
+    uint32_t c, f, cf, t0;     // t0: stream index of the lane's first tile
+    uint32_t ty, tx;           // its tile row and column
     bool valid, hasA, hasB;
 };
 
@@ -355,50 +356,33 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
     k.valid = c < p.n_chunks;
     k.f = k.valid ? c / p.chunks_per_frame : 0u;
     k.cf = k.valid ? c - k.f * p.chunks_per_frame : 0u;
-    k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
-    k.hasA = k.valid && k.t0 < p.T;
-    k.hasB = k.valid && k.t0 + 1u < p.T;
+    if (p.lanes_per_row == 0u) {            // plain: 1024 consecutive tiles
+        k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
+        k.hasA = k.valid && k.t0 < p.T;
+        k.hasB = k.valid && k.t0 + 1u < p.T;
+        k.ty = k.t0 / p.w;
+        k.tx = k.t0 - k.ty * p.w;
+    } else {                                // the lane's pair: tile row = pair / lanes_per_row
+        const uint32_t pair = k.cf * (kEncChunkTiles / 2u) + (uint32_t)tidw;
+        k.ty = pair / p.lanes_per_row;
+        k.tx = 2u * (pair - k.ty * p.lanes_per_row);
+        k.t0 = k.ty * p.w + k.tx;
+        k.hasA = k.valid && k.ty < p.h;
+        k.hasB = k.hasA && k.tx + 1u < p.w;
+    }
     return k;
 }
 
-// Branch-free half of load_tile_generic for W >= 8: the 8 bytes ending at the tile row's last valid pixel.
-__device__ __forceinline__ void load_tile_generic_raw(const uint8_t *img, int W, int H, uint32_t w, uint32_t t,
-                                                      uint32_t (&v)[16]) {
-    const uint32_t ty = t / w, tx = t - ty * w;
-    const int x0 = 8 * (int)tx;
-    const int rm = W - x0 < 8 ? W - x0 : 8;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        int yy = 8 * (int)ty + r;
-        yy = yy < H ? yy : H - 1;   // bottom padding = repeat the last row
-        const uint64_t q = load_u64_any(img + (size_t)yy * (size_t)W + (size_t)(x0 + rm - 8));
-        v[2 * r] = (uint32_t)q;
-        v[2 * r + 1] = (uint32_t)(q >> 32);
-    }
-}
-__device__ __forceinline__ void fixup_tile_generic(int W, uint32_t w, uint32_t t, bool has, uint32_t (&v)[16]) {
-    const uint32_t ty = t / w, tx = t - ty * w;
-    const int x0 = 8 * (int)tx;
-    const int rm = W - x0 < 8 ? W - x0 : 8;
-    if (!has) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = 0;
-    } else if (rm < 8) {   // right margin: valid pixels down to byte 0, the last one repeated
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint64_t q = (((uint64_t)v[2 * r + 1] << 32) | v[2 * r]) >> (8 * (8 - rm));
-            const uint64_t last = (q >> (8 * (rm - 1))) & 0xFFull;
-            q |= (last * 0x0101010101010101ull) << (8 * rm);
-            v[2 * r] = (uint32_t)q;
-            v[2 * r + 1] = (uint32_t)(q >> 32);
-        }
-    }
-}
-
-// IN_MODE: how a chunk's pixels are fetched.  kInFast: W % 16 == 0 and a 16-byte aligned base (one
-// 16-byte load per row and lane); kInRaw: any geometry with W >= 8 (branch-free 8-byte loads, fixed up
-// when consumed); kInBytes: images narrower than one tile (byte by byte).  A template parameter, not a
-// run-time branch: the number of loads a step issues must be static for them to stay in flight.
+// IN_MODE: how a chunk's pixels are fetched.
+//   kInFast : W % 16 == 0 and a 16-byte aligned base: one aligned 16-byte load per image row and lane.
+//   kInRaw  : any geometry with W >= 16: ONE (unaligned) 16-byte load per image row and lane as well -- the lane's
+//             two tiles are neighbours in one tile row by construction (chunk_ref).  Near the right edge
+//             the 16 bytes that END at the row's last pixel are fetched instead (always inside the image) and
+//             shifted into place, padded (dbde_util.cpp:116-132) or dropped when they are consumed.  Unaligned
+//             reads cost 8 %; two 8-byte loads per row (round 1) cost twice the vector-memory instructions.
+//   kInBytes: images narrower than 16 pixels (byte by byte).
+// A template parameter, not a run-time branch: the number of loads a step issues must be static for them to
+// stay in flight.
 constexpr int kInFast = 0, kInRaw = 1, kInBytes = 2;
 
 template <int IN_MODE, bool ZERO = true>
@@ -409,44 +393,67 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
         for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
     }
     const uint8_t *img = p.images + (size_t)k.f * p.frame_pixels;
-    if (IN_MODE == kInFast) {   // W % 16 == 0, base 16-aligned: both tiles in one strip, one 16-B load per row
+    if (IN_MODE == kInFast || IN_MODE == kInRaw) {
         // No branch around the loads: a lane without tiles reads tile 0 of frame 0 and nobody looks
         // at the result.  With a conditional issue the compiler cannot know how many loads are in
         // flight and makes the statistics of the CURRENT chunk wait for these as well.
-        const uint32_t t = k.hasA ? k.t0 : 0u;
-        const uint32_t ty = t / p.w, tx = t - ty * p.w;
-        const uint8_t *base = img + (size_t)(8u * tx);
+        const uint32_t ty = k.hasA ? k.ty : 0u, tx = k.hasA ? k.tx : 0u;
+        uint32_t x0 = 8u * tx;
+        if (IN_MODE == kInRaw) x0 = x0 + 16u <= (uint32_t)p.W ? x0 : (uint32_t)p.W - 16u;   // stay inside the row
+        const uint8_t *base = img + (size_t)x0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int yy = 8 * (int)ty + r;
             yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
-            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(base + (size_t)yy * (size_t)p.W);
-            const u32x4_t q = DBDE_NT ? __builtin_nontemporal_load(src) : *src;
+            const uint8_t *src = base + (size_t)yy * (size_t)p.W;
+            u32x4_t q;
+            if (IN_MODE == kInFast) {
+                q = DBDE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(src))
+                            : *reinterpret_cast<const u32x4_t *>(src);
+            } else {   // any byte alignment: global memory takes it, the compiler must be told
+                typedef u32x4_t __attribute__((aligned(1))) u32x4_unaligned;
+                q = DBDE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(src))
+                            : *reinterpret_cast<const u32x4_unaligned *>(src);
+            }
             va[2 * r] = q[0]; va[2 * r + 1] = q[1];
             vb[2 * r] = q[2]; vb[2 * r + 1] = q[3];
         }
-    } else {
-        if (IN_MODE == kInRaw) {
-            // Straight-line, branch-free loads so that they can stay in flight until the next step:
-            // every lane reads 8 bytes per row and tile at an in-bounds address -- for a right-margin
-            // tile the 8 bytes that END at its last valid pixel -- and load_fixup_generic() shifts,
-            // pads (dbde_util.cpp:116-132) or zeroes them when they are consumed.
-            load_tile_generic_raw(img, p.W, p.H, p.w, k.hasA ? k.t0 : 0u, va);
-            load_tile_generic_raw(img, p.W, p.H, p.w, k.hasB ? k.t0 + 1u : 0u, vb);
-        } else {   // images narrower than one tile: byte by byte
-            if (k.hasA) load_tile_generic(img, p.W, p.H, p.w, k.t0, va);
-            if (k.hasB) load_tile_generic(img, p.W, p.H, p.w, k.t0 + 1u, vb);
-        }
+    } else {   // images narrower than two tiles: byte by byte
+        if (k.hasA) load_tile_generic(img, p.W, p.H, p.w, k.t0, va);
+        if (k.hasB) load_tile_generic(img, p.W, p.H, p.w, k.t0 + 1u, vb);
     }
 }
 
-// Second half of the generic load (see load_chunk): applied to the registers of `k` when they are used.
+// Second half of the kInRaw load (see load_chunk): applied to the registers of `k` when they are used.  Only the
+// last lane(s) of an image row have anything to do, so the work sits behind a wave-uniform test.
 template <int IN_MODE>
 __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                                    uint32_t (&vb)[16]) {
     if (IN_MODE != kInRaw) return;
-    fixup_tile_generic(p.W, p.w, k.t0, k.hasA, va);
-    fixup_tile_generic(p.W, p.w, k.t0 + 1u, k.hasB, vb);
+    const uint32_t x0 = 8u * k.tx, W = (uint32_t)p.W;
+    const uint32_t sh = k.hasA && x0 + 16u > W ? x0 + 16u - W : 0u;           // bytes the fetch was moved left
+    const uint32_t rmA = !k.hasA ? 0u : (W - x0 < 8u ? W - x0 : 8u);          // valid columns of the two tiles
+    const uint32_t rmB = !k.hasB ? 0u : (W - x0 - 8u < 8u ? W - x0 - 8u : 8u);
+    if (__all((int)(!k.hasA || (rmA == 8u && rmB == 8u)))) return;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint64_t lo = ((uint64_t)va[2 * r + 1] << 32) | va[2 * r], hi = ((uint64_t)vb[2 * r + 1] << 32) | vb[2 * r];
+        if (sh >= 8u) { lo = hi >> (8u * (sh - 8u)); hi = 0; }
+        else if (sh != 0u) { lo = (lo >> (8u * sh)) | (hi << (64u - 8u * sh)); hi >>= 8u * sh; }
+        // constant padding to the right: the last valid pixel repeated (dbde_util.cpp:116-128)
+        if (rmA < 8u && rmA != 0u) {
+            lo &= ~0ull >> (64u - 8u * rmA);
+            lo |= (((lo >> (8u * (rmA - 1u))) & 0xFFull) * 0x0101010101010101ull) << (8u * rmA);
+        }
+        if (rmB < 8u && rmB != 0u) {
+            hi &= ~0ull >> (64u - 8u * rmB);
+            hi |= (((hi >> (8u * (rmB - 1u))) & 0xFFull) * 0x0101010101010101ull) << (8u * rmB);
+        }
+        if (rmA == 0u) lo = 0;
+        if (rmB == 0u) hi = 0;
+        va[2 * r] = (uint32_t)lo; va[2 * r + 1] = (uint32_t)(lo >> 32);
+        vb[2 * r] = (uint32_t)hi; vb[2 * r + 1] = (uint32_t)(hi >> 32);
+    }
 }
 
 // One tile row -> 8*d-bit integer with two v_dot4_u32_u8 per 4 pixels (weights 1, 2^d);
@@ -776,7 +783,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
 #endif
 }
 
-static int in_mode_of(const EncParams &p, bool fast_in) { return fast_in ? kInFast : (p.W >= 8 ? kInRaw : kInBytes); }
+static int in_mode_of(const EncParams &p, bool fast_in) { return fast_in ? kInFast : (p.lanes_per_row ? kInRaw : kInBytes); }
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
     dim3 block(kEncThreads);

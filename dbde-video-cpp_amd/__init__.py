@@ -36,7 +36,7 @@ C_ABI_SYMBOLS = [
     "dbde_hip_create", "dbde_hip_destroy", "dbde_hip_sync", "dbde_hip_last_error", "dbde_hip_device_arch",
     "dbde_hip_max_frame_bytes", "dbde_hip_image_bytes",
     "dbde_hip_encode_frames", "dbde_hip_decode_frames", "dbde_hip_index_stream", "dbde_hip_index_stream_async",
-    "dbde_hip_synth_frames",
+    "dbde_hip_scan_ahead", "dbde_hip_scan_join", "dbde_hip_synth_frames",
     "dbde_hip_pack_8x8", "dbde_hip_pack_8x8_partial", "dbde_hip_pack_image", "dbde_hip_pack_frame",
     "dbde_hip_unpack_8x8", "dbde_hip_unpack_8x8_partial", "dbde_hip_unpack_image", "dbde_hip_unpack_frame",
     "dbde_hip_pack_frame_header", "dbde_hip_pack_video_header",
@@ -105,6 +105,10 @@ def lib():
     L.dbde_hip_index_stream.argtypes = [vp, vp, sz, i, i, i, vp, C.POINTER(i)]
     L.dbde_hip_index_stream_async.restype = i
     L.dbde_hip_index_stream_async.argtypes = [vp, vp, sz, i, i, i, vp, vp]
+    L.dbde_hip_scan_ahead.restype = i
+    L.dbde_hip_scan_ahead.argtypes = [vp, vp, sz, i, i, i, vp, vp, vp]
+    L.dbde_hip_scan_join.restype = i
+    L.dbde_hip_scan_join.argtypes = [vp]
     L.dbde_hip_synth_frames.restype = i
     L.dbde_hip_synth_frames.argtypes = [vp, i, u64, u64, i, i, i, vp]
     L.dbde_hip_pack_8x8.restype = C.c_uint32
@@ -298,6 +302,16 @@ class Codec:
                                                 max_frames, offsets.data_ptr(), count.data_ptr())
         self._check(rc, "dbde_hip_index_stream_async")
         return offsets, count
+
+    def scan_ahead(self, stream, stream_offset, stream_bytes, W, H, max_frames, cursor, offsets, count):
+        """Enqueues the walk of the next batch on the context's second stream (see dbde_hip.h): `cursor`
+        (int64 device tensor, 1 element, zeroed before the first call) is advanced past the frames found."""
+        rc = self.L.dbde_hip_scan_ahead(self.h, stream.data_ptr() + stream_offset, stream_bytes, W, H, max_frames,
+                                        cursor.data_ptr(), offsets.data_ptr(), count.data_ptr())
+        self._check(rc, "dbde_hip_scan_ahead")
+
+    def scan_join(self):
+        self._check(self.L.dbde_hip_scan_join(self.h), "dbde_hip_scan_join")
 
     @staticmethod
     def parse_results(results):

@@ -41,6 +41,10 @@ struct dbde_hip_ctx {
     // look-back workspace: [ctrl: 4 x u32][state: n_chunks x u64], zeroed before every encode
     uint8_t *lb = nullptr;
     size_t lb_bytes = 0;
+    // scan-ahead: a second stream so that the frame-to-frame walk of the NEXT batch runs beside the decode of this one
+    hipStream_t scan_stream = nullptr;
+    hipEvent_t scan_ev_main = nullptr, scan_ev_done = nullptr;
+    bool lb_clean = false;           // records and counters are all zero (small launches leave them so)
     // decode workspace
     uint32_t *chunk_off = nullptr;
     size_t chunk_off_n = 0;
@@ -184,6 +188,9 @@ void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    if (ctx->scan_stream) { (void)hipStreamSynchronize(ctx->scan_stream); (void)hipStreamDestroy(ctx->scan_stream); }
+    if (ctx->scan_ev_main) (void)hipEventDestroy(ctx->scan_ev_main);
+    if (ctx->scan_ev_done) (void)hipEventDestroy(ctx->scan_ev_done);
     if (ctx->lb) (void)hipFree(ctx->lb);
     if (ctx->chunk_off) (void)hipFree(ctx->chunk_off);
     if (ctx->frame_ok) (void)hipFree(ctx->frame_ok);
@@ -201,6 +208,7 @@ int dbde_hip_sync(dbde_hip_ctx *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (flag) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->sticky, 0, 4, ctx->stream));
+        ctx->lb_clean = false;   // a kernel gave up: its records may be left behind
         return fail(ctx, DBDE_HIP_ERR_DEVICE, "encode kernel: chunk look-back timed out");
     }
     return DBDE_HIP_OK;
@@ -266,11 +274,16 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     const uint32_t n_chunks = (uint32_t)n_chunks64;
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
     {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
+        const size_t had = ctx->lb_bytes;
         int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);
         if (rc) return rc;
+        if (ctx->lb_bytes != had) ctx->lb_clean = false;
     }
+    // small launches (one frame per call above all): one workgroup per chunk, self-cleaning workspace, no memset
+    const bool small = n_chunks < ctx->enc_grid;
     span_begin(ctx, 0);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
+    if (!small || !ctx->lb_clean) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
+    ctx->lb_clean = small;
 
     EncParams p;
     p.images = d_images;
@@ -298,7 +311,8 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
                              (slot_stride % 8 == 0);
-    HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
+    if (small) HIP_TRY(ctx, launch_encode_small(p, fast_in, aligned_out, ctx->stream));
+    else HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;
 }
@@ -333,44 +347,51 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     const uint64_t n_chunks64 = (uint64_t)n_frames * dcpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64 + (size_t)n_frames, sizeof(uint32_t));
-    if (rc) return rc;
-    rc = grow(ctx, ctx->frame_ok, ctx->frame_ok_n, (size_t)n_frames, sizeof(uint32_t));
-    if (rc) return rc;
+    // Small frames (the tile-level entry points, thumbnails): the decode workgroups index the frame themselves --
+    // each reads the T depth bytes -- and the index kernel with its launch boundary is gone.  Only while T is a
+    // couple of loads per thread: for a 4096x3072 frame (T = 196,608, 384 workgroups re-reading it) the same
+    // idea took 38 us against 11 us for index + decode, measured.
+    const bool self_index = g.T <= 8192u && n_chunks64 * (uint64_t)g.T <= (8ull << 20);
+    if (!self_index) {
+        int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64 + (size_t)n_frames, sizeof(uint32_t));
+        if (rc) return rc;
+        rc = grow(ctx, ctx->frame_ok, ctx->frame_ok_n, (size_t)n_frames, sizeof(uint32_t));
+        if (rc) return rc;
 
-    IdxParams ip;
-    ip.stream = d_stream;
-    ip.frame_offsets = d_frame_offsets;
-    ip.stream_bytes = stream_bytes;
-    ip.chunk_off = ctx->chunk_off;
-    ip.frame_ok = ctx->frame_ok;
-    ip.results = d_results;
-    ip.T = g.T;
-    ip.chunks_per_frame = dcpf;
-    ip.geom = dg;
-    // Few frames: cut each frame into pieces so that the index pass fills the device too
-    // (>= 4 chunks per piece, about 1024 workgroups in all); from 256 frames on, one workgroup per frame.
-    ip.split = 1;
-    ip.frame_ctr = nullptr;
-    ip.frame_flag = nullptr;
-    if (n_frames < 256 && dcpf >= 8u) {
-        uint32_t sp = 1024u / (uint32_t)n_frames;
-        const uint32_t most = (dcpf + 3u) / 4u;
-        if (sp > most) sp = most;
-        if (sp > 1u) {
-            const size_t before = ctx->idx_ctr_n;
-            rc = grow(ctx, ctx->idx_ctr, ctx->idx_ctr_n, 2 * (size_t)n_frames, sizeof(uint32_t));
-            if (rc) return rc;
-            if (ctx->idx_ctr_n != before)   // fresh block: the kernel keeps it zero from here on
-                HIP_TRY(ctx, hipMemsetAsync(ctx->idx_ctr, 0, ctx->idx_ctr_n * sizeof(uint32_t), ctx->stream));
-            ip.split = sp;
-            ip.frame_ctr = ctx->idx_ctr;
-            ip.frame_flag = ctx->idx_ctr + n_frames;
+        IdxParams ip;
+        ip.stream = d_stream;
+        ip.frame_offsets = d_frame_offsets;
+        ip.stream_bytes = stream_bytes;
+        ip.chunk_off = ctx->chunk_off;
+        ip.frame_ok = ctx->frame_ok;
+        ip.results = d_results;
+        ip.T = g.T;
+        ip.chunks_per_frame = dcpf;
+        ip.geom = dg;
+        // Few frames: cut each frame into pieces so that the index pass fills the device too
+        // (>= 4 chunks per piece, about 1024 workgroups in all); from 256 frames on, one workgroup per frame.
+        ip.split = 1;
+        ip.frame_ctr = nullptr;
+        ip.frame_flag = nullptr;
+        if (n_frames < 256 && dcpf >= 8u) {
+            uint32_t sp = 1024u / (uint32_t)n_frames;
+            const uint32_t most = (dcpf + 3u) / 4u;
+            if (sp > most) sp = most;
+            if (sp > 1u) {
+                const size_t before = ctx->idx_ctr_n;
+                rc = grow(ctx, ctx->idx_ctr, ctx->idx_ctr_n, 2 * (size_t)n_frames, sizeof(uint32_t));
+                if (rc) return rc;
+                if (ctx->idx_ctr_n != before)   // fresh block: the kernel keeps it zero from here on
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->idx_ctr, 0, ctx->idx_ctr_n * sizeof(uint32_t), ctx->stream));
+                ip.split = sp;
+                ip.frame_ctr = ctx->idx_ctr;
+                ip.frame_flag = ctx->idx_ctr + n_frames;
+            }
         }
+        span_begin(ctx, 1);
+        HIP_TRY(ctx, launch_decode_index(ip, n_frames, ctx->stream));
+        span_end(ctx);
     }
-    span_begin(ctx, 1);
-    HIP_TRY(ctx, launch_decode_index(ip, n_frames, ctx->stream));
-    span_end(ctx);
 
     DecParams p;
     p.stream = d_stream;
@@ -379,6 +400,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.images = d_images;
     p.chunk_off = ctx->chunk_off;
     p.frame_ok = ctx->frame_ok;
+    p.results = d_results;
     p.frame_pixels = g.pixels;
     p.W = W;
     p.H = H;
@@ -389,7 +411,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.n_chunks = (uint32_t)n_chunks64;
     p.geom = dg;
     span_begin(ctx, 2);
-    HIP_TRY(ctx, launch_decode(p, img_mode, ctx->stream));
+    HIP_TRY(ctx, launch_decode(p, img_mode, self_index, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;
 }
@@ -402,8 +424,47 @@ int dbde_hip_index_stream_async(dbde_hip_ctx *ctx, const uint8_t *d_stream, size
         return fail(ctx, DBDE_HIP_ERR_ARG, "index_stream: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     span_begin(ctx, 3);
-    HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, ctx->stream));
+    HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, nullptr, ctx->stream));
     span_end(ctx);
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_scan_ahead(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W, int H, int max_frames,
+                        uint64_t *d_cursor, uint64_t *d_frame_offsets, uint32_t *d_n_found) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    Geometry g;
+    if (!d_stream || !d_frame_offsets || !d_n_found || !d_cursor || max_frames < 0 || !geometry(W, H, g))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "scan_ahead: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->scan_stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->scan_stream, hipStreamNonBlocking, hi));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->scan_ev_main, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->scan_ev_done, hipEventDisableTiming));
+    }
+    // the walk may read what the main stream has produced so far (and the cursor a previous walk left)
+    HIP_TRY(ctx, hipEventRecord(ctx->scan_ev_main, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->scan_stream, ctx->scan_ev_main, 0));
+    if (ctx->timing) {
+        TimedSpan sp;
+        sp.kind = 3;
+        if (hipEventCreate(&sp.a) == hipSuccess && hipEventCreate(&sp.b) == hipSuccess) {
+            (void)hipEventRecord(sp.a, ctx->scan_stream);
+            HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, d_cursor, ctx->scan_stream));
+            (void)hipEventRecord(sp.b, ctx->scan_stream);
+            ctx->spans.push_back(sp);
+        }
+    } else {
+        HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, d_cursor, ctx->scan_stream));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->scan_ev_done, ctx->scan_stream));
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_scan_join(dbde_hip_ctx *ctx) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    if (ctx->scan_stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->scan_ev_done, 0));
     return DBDE_HIP_OK;
 }
 
@@ -626,6 +687,7 @@ int dbde_hip_timing_enable(dbde_hip_ctx *ctx, int on) {
 int dbde_hip_timing_read(dbde_hip_ctx *ctx, double ms[4], uint64_t launches[4], int reset) {
     if (!ctx) return DBDE_HIP_ERR_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scan_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->scan_stream));
     for (auto &s : ctx->spans) {
         float t = 0;
         if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {

@@ -96,6 +96,7 @@ struct DecParams {
     uint8_t *images;
     const uint32_t *chunk_off;      // [n_frames][chunks_per_frame + 1] payload word offset of each chunk inside its frame (+ total)
     const uint32_t *frame_ok;       // [n_frames] 1 = frame data validated
+    void *results;                  // optional dbde_hip_frame_result[n_frames] (written by the self-indexing form)
     uint64_t frame_pixels;
     int W, H;
     uint32_t w, h, T;
@@ -126,15 +127,19 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 };
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
+// Launches with at most as many chunks as the device holds workgroups: one workgroup per chunk, no scanner,
+// self-cleaning workspace (records and counters are zero on entry and on exit).
+hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
-hipError_t launch_decode(const DecParams &p, int img_mode, hipStream_t s);
+// self_index: no index kernel ran; every workgroup validates the frame and finds its offset itself (few frames)
+hipError_t launch_decode(const DecParams &p, int img_mode, bool self_index, hipStream_t s);
 hipError_t launch_synth(int mode, uint64_t seed, uint64_t first_frame, int n_frames, int W, int H,
                         uint8_t *d_images, hipStream_t s);
 // Serial frame-to-frame hop over a concatenated stream (one wave); see dbde_hip_index_stream.
 hipError_t launch_scan_stream(const uint8_t *stream, uint64_t stream_bytes, uint32_t T, int max_frames,
-                              uint64_t *d_offsets, uint32_t *d_count, hipStream_t s);
+                              uint64_t *d_offsets, uint32_t *d_count, uint64_t *d_cursor, hipStream_t s);
 // Maximum chunks_per_frame the decode index kernel can hold in LDS.
 constexpr uint32_t kMaxChunksPerFrame = 32768;
 

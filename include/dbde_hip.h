@@ -128,6 +128,18 @@ int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t str
 int dbde_hip_index_stream_async(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W,
                                 int H, int max_frames, uint64_t *d_frame_offsets, uint32_t *d_n_found);
 
+/* Reading an un-indexed stream a batch at a time without the walk on the critical path: dbde_hip_scan_ahead
+ * enqueues the walk of the next (up to) max_frames frames on a SECOND stream owned by the context -- behind
+ * everything enqueued on the context's stream so far -- starting at the byte offset in the device word *d_cursor
+ * and leaving the offset of the first unvisited byte there (zero it before the first call); frame offsets are
+ * relative to d_stream.  dbde_hip_scan_join makes the context's stream wait for the walks enqueued so far.
+ * A reader enqueues: scan_ahead(batch 0); then per batch b: scan_join, scan_ahead(batch b+1), decode_frames(batch b)
+ * -- the dependent pointer chase of batch b+1 (about a microsecond per frame) then runs beside the decode of b. */
+int dbde_hip_scan_ahead(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W, int H,
+                        int max_frames, uint64_t *d_cursor, uint64_t *d_frame_offsets,
+                        uint32_t *d_n_found);
+int dbde_hip_scan_join(dbde_hip_ctx *ctx);
+
 /* Counter-based synthetic frames (same bytes as oracle/synth.c): mode 0 noise8, 1 mixed,
  * 2 flat, 3 smooth.  Used by bench.py and the parity tests to build inputs in HBM. */
 int dbde_hip_synth_frames(dbde_hip_ctx *ctx, int mode, uint64_t seed, uint64_t first_frame,

@@ -238,6 +238,39 @@ def test_index_stream(codec):
     assert torch.equal(back, imgs)
 
 
+def test_scan_ahead_reader_pipeline(codec):
+    """dbde_hip_scan_ahead / dbde_hip_scan_join: an un-indexed stream read a batch at a time, the walk of the next
+    batch on the context's second stream beside the decode of the current one; uneven last batch, cursor carried
+    across calls, a truncated tail ends the walk."""
+    import torch
+    W, H, n, per = 200, 123, 23, 5
+    imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+    frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n)
+    total = int((offs[-1] + sizes[-1]).item())
+    dev = imgs.device
+    for stream_bytes, want in ((total, n), (total - 3, n - 1)):
+        cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        nb = (n + per - 1) // per
+        found = torch.full((nb * per,), -1, dtype=torch.int64, device=dev)
+        counts = torch.zeros(nb, dtype=torch.int32, device=dev)
+        out = torch.full_like(imgs, 0xEE)
+        codec.scan_ahead(buf, lead, stream_bytes, W, H, per, cursor, found[0:per], counts[0:1])
+        for b in range(nb):
+            codec.scan_join()
+            if b + 1 < nb:
+                codec.scan_ahead(buf, lead, stream_bytes, W, H, per, cursor, found[(b + 1) * per:(b + 2) * per],
+                                 counts[b + 1:b + 2])
+            k = min(per, n - b * per)
+            # a reader that expects k frames decodes k; entries the walk did not reach are rejected (offset -1 is
+            # outside the stream), never decoded from garbage
+            codec.decode_frames(buf, lead, stream_bytes, found[b * per:b * per + k], W, H, k, images=out[b * per:b * per + k])
+        codec.sync()
+        assert int(counts.sum().item()) == want
+        assert torch.equal(found[:want], offs[:want]) and (found[want:] == -1).all()
+        assert torch.equal(out[:want], imgs[:want]) and (out[want:] == 0xEE).all()
+        assert int(cursor.item()) == int((offs[want - 1] + sizes[want - 1]).item())
+
+
 @pytest.mark.parametrize("W,H,n,mode", [(200, 123, 3, "mixed"), (8, 8, 1, "noise8"), (9, 9, 2, "mixed"),
                                         (4096, 24, 1, "noise8"), (1, 1, 1, "flat"), (24, 8, 1, "noise8")])
 def test_decode_reads_nothing_past_stream_bytes(codec, W, H, n, mode):

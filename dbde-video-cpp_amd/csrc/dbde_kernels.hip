@@ -471,11 +471,6 @@ __device__ __forceinline__ uint64_t pack_row_dot(uint32_t lo, uint32_t hi, uint3
 // wave's LDS region starting at word q.
 __device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, uint32_t d, uint64_t *pay, uint32_t q) {
     const uint32_t m4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
-#ifdef DBDE_EXP_NOPACK   // A/B only (wrong bytes): what the bit packing costs
-#pragma unroll
-    for (int r = 0; r < 8; r++) if ((uint32_t)r < d) pay[swzq8(q + (uint32_t)r)] = ((uint64_t)(v[2 * r + 1] - m4) << 32) | (v[2 * r] - m4);
-    return;
-#endif
     const uint32_t w_lo = 1u | ((1u << d) << 8), w_hi = w_lo << 16;
     const bool is8 = d >= 8u;
     Funnel fn;

@@ -24,7 +24,7 @@ def read_csvs(pattern):
 def main():
     d = sys.argv[1].rstrip("/")
     tag = os.path.basename(d).replace("prof_", "")
-    content = tag.split("_")[-1]
+    content = "_".join(tag.split("_")[-2:])        # cfg<N>_<content>: the key bench.py looks up
     out = []
     # 1. kernel trace
     kt = read_csvs(os.path.join(d, "kt", "**", "*kernel_trace.csv"))
@@ -46,9 +46,8 @@ def main():
             for c, v in acc[k].items():
                 avg = sum(v) / len(v)
                 out.append(f"{k[:70]:70s} {c:24s} {avg:18.1f} {len(v):6d}")
-                if c in ("FETCH_SIZE", "WRITE_SIZE") and ("dbde::encode_" in k or "dbde::decode_kernel" in k):
-                    name = ("dbde::encode_framewise_kernel" if "encode_framewise" in k else
-                            "dbde::encode_kernel" if "encode_kernel" in k else "dbde::decode_kernel")
+                if c in ("FETCH_SIZE", "WRITE_SIZE") and ("dbde::encode_kernel" in k or "dbde::decode_kernel" in k):
+                    name = "dbde::encode_kernel" if "encode_kernel" in k else "dbde::decode_kernel"
                     traffic.setdefault(name, {})[c] = avg
     for name, t in traffic.items():
         if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
@@ -62,10 +61,17 @@ def main():
     tf = os.path.join(here, "hbm_traffic.json")
     cur = json.load(open(tf)) if os.path.exists(tf) else {}
     cur[content] = {k: int(v["bytes"]) for k, v in traffic.items() if "bytes" in v}
-    # frames per launch of the profiled run: raw image bytes written by the decoder / frame size
-    dec = traffic.get("dbde::decode_kernel", {})
-    if "WRITE_SIZE" in dec:
-        cur[content]["frames_per_launch"] = int(round(dec["WRITE_SIZE"] * 1024 / (4096 * 3072)))
+    # the workload and the kernel sources this record belongs to (bench.py replays it only when both match)
+    line = os.path.join(d, "bench_line.json")
+    if os.path.exists(line):
+        try:
+            cur[content]["frames_per_launch"] = json.load(open(line))["config"]["frames_per_step_per_gpu"]
+        except Exception:
+            pass
+    sys.path.insert(0, os.path.dirname(here))
+    import bench
+    cur["kernels_sha"] = bench.kernels_fingerprint()
+    cur["tag"] = tag.split("_")[0]
     json.dump(cur, open(tf, "w"), indent=1)
     print("\n".join(out))
 

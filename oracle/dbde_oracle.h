@@ -80,6 +80,14 @@ double dbde_oracle_time_roundtrip(const uint8_t *images, int n, int W, int H, in
                                   uint8_t *scratch_packed, uint8_t *scratch_image,
                                   double *enc_seconds, double *dec_seconds, uint64_t *mismatch);
 
+/* ---- DBDE16: the higher-bit-depth extension README.md:65 points at (oracle/dbde16_oracle.c holds the
+ * specification).  PARITY UNPINNED: the reference defines no such format; tied to the pinned 8-bit oracle on
+ * images that fit 8 bits (tests/test_oracle_u16.py). */
+size_t dbde16_oracle_max_frame_bytes(int W, int H);
+size_t dbde16_oracle_pack_image(const uint16_t *image, int W, int H, uint8_t *target);
+size_t dbde16_oracle_pack_frame(uint64_t index, const uint16_t *image, int W, int H, uint8_t *target);
+size_t dbde16_oracle_unpack_image(const uint8_t *packed, int W, int H, uint16_t *image);
+
 #ifdef __cplusplus
 }
 #endif

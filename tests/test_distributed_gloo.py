@@ -57,6 +57,28 @@ def _worker(rank, world, port, q):
             at += adv
             n += 1
         q.put(bool(ok and n == N))
+    # the pipelined form (what the streaming driver does per batch): the gather of batch k is posted and only
+    # waited for after batch k+1 has been posted, into two alternating root windows
+    batches = [frames[i:i + 2] for i in range(0, len(frames), 2)]
+    windows = [torch.empty(4096, dtype=torch.uint8) for _ in range(2)] if rank == 0 else [None, None]
+    pending, got_batches, okp = None, [], True
+    for kb, bf in enumerate(batches + [None]):
+        if bf is not None:
+            segb = torch.from_numpy(np.concatenate(bf + [np.zeros(8, np.uint8)]))
+            nb = sum(len(f) for f in bf)
+            view, szs, works = dd.gather_stream_begin(segb, nb, dst=0, out=windows[kb % 2], max_message_bytes=113)
+            posted = (view, szs, works, segb)
+        if pending is not None:
+            dd.gather_stream_end(pending[2])
+            if rank == 0:
+                got_batches.append((pending[0].clone(), pending[1]))
+        pending = posted if bf is not None else None
+    if rank == 0:
+        # batch k of the gathered result = rank 0's batch k followed by rank 1's batch k
+        for kb, (view, szs) in enumerate(got_batches):
+            mine = np.concatenate(batches[kb]) if kb < len(batches) else np.zeros(0, np.uint8)
+            okp = okp and view[:szs[0]].numpy().tobytes() == mine.tobytes() and sum(szs) == view.numel()
+        q.put(("pipelined", bool(okp and len(got_batches) == len(batches))))
     # decode side: the root scatters frame blocks of the gathered stream back out; every rank
     # decodes its own block (the oracle standing in for the GPU decoder) and finds its frames
     if rank == 0:
@@ -96,6 +118,7 @@ def test_gather_and_scatter_stream_world2_gloo():
     [p.start() for p in procs]
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    got = [q.get(timeout=5) for _ in range(3)]
+    got = [q.get(timeout=5) for _ in range(4)]
     assert True in got                                     # rank 0: the gathered stream is the full stream
-    assert sorted(g for g in got if isinstance(g, tuple)) == [("scatter", 0, True), ("scatter", 1, True)]
+    assert ("pipelined", True) in got                      # rank 0: overlapped per-batch gathers, two windows
+    assert sorted(g for g in got if isinstance(g, tuple) and g[0] == "scatter") == [("scatter", 0, True), ("scatter", 1, True)]

@@ -299,7 +299,8 @@ class Bench:
             else:
                 rts = RoundTripStream(self.codec, W, H, batch, source=source, source_stream=side, gather=g)
             self.fence()
-            r = rts.run(lo, hi - lo, self.world, self.rank)
+            rounds = -(-(-(-n_total // self.world)) // batch)      # batches of the largest rank block
+            r = rts.run(lo, hi - lo, self.world, self.rank, rounds=rounds)
             t = torch.tensor([r["seconds"]], dtype=torch.float64, device=self.dev)
             if self.dist is not None:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -378,7 +379,9 @@ def main():
     dist = None
     # rehearsal on a one-GPU box: DBDE_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo (exercises the
     # launch contract, sharding, barrier, max-over-ranks and the staged gather pipeline; not a measurement)
-    rehearsal = os.environ.get("DBDE_BENCH_REHEARSAL") == "1"
+    # (DBDE_BENCH_REHEARSAL=nccl: the same with the RCCL backend, where the runtime accepts two ranks on one device)
+    rehearsal = os.environ.get("DBDE_BENCH_REHEARSAL") in ("1", "nccl")
+    rehearsal_nccl = os.environ.get("DBDE_BENCH_REHEARSAL") == "nccl"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -387,7 +390,10 @@ def main():
         elif rehearsal:
             local = 0
             torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
+            if rehearsal_nccl:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+            else:
+                dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -407,7 +413,7 @@ def main():
     cfg = dict(CONFIGS[args.config])
     W, H = cfg["W"], cfg["H"]
     content = args.content or cfg["content"]
-    gather_mode = None if (dist is None or args.no_gather) else ("host" if rehearsal else "nccl")
+    gather_mode = None if (dist is None or args.no_gather) else ("host" if rehearsal and not rehearsal_nccl else "nccl")
 
     line = {"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "unit": "frames/s",
             "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,

@@ -337,7 +337,7 @@ constexpr int kEncThreads = 64 * kEncWaves;
 constexpr uint32_t kWaveWords = 128 * 8;                         // 1024 U64 = 8 KiB per wave
 
 struct EncShared {
-    uint64_t pay[kEncWaves][kWaveWords];     // swizzled (swzq8) payload image of each wave
+    uint64_t pay[kEncWaves][kWaveWords + 64];   // swizzled (swzq8) payload image of each wave + a trash word per lane
     uint32_t tot[2][kEncWaves];              // [parity][wave] payload words of cur per wave
     uint32_t lb[2][4];                       // [parity] {in-frame prefix, launch prefix, ok, next chunk id}
     uint32_t acc[2];                         // [parity] arrivals << 24 | sum of the waves' totals
@@ -468,18 +468,30 @@ __device__ __forceinline__ uint64_t pack_row_dot(uint32_t lo, uint32_t hi, uint3
 }
 
 // Subtract the minimum, pack each row to 8*d bits, concatenate rows into d U64 words of the
-// wave's LDS region starting at word q.
-__device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, uint32_t d, uint64_t *pay, uint32_t q) {
+// wave's LDS region starting at word q.  Straight-line: EVERY row stores the word it is filling -- a word that
+// is not complete yet is simply stored again by the next row with more bits in it -- so there is no branch on
+// "did this row complete a word" (sixteen exec-mask regions per lane and step in round 1).  A tile without
+// payload (d == 0) stores into the lane's own trash word behind the image instead.
+__device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, uint32_t d, uint64_t *pay, uint32_t q,
+                                          uint32_t trash) {
     const uint32_t m4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
     const uint32_t w_lo = 1u | ((1u << d) << 8), w_hi = w_lo << 16;
     const bool is8 = d >= 8u;
-    Funnel fn;
-    fn.reset();
+    const uint32_t nb = 8u * d;
+    uint32_t qq = d ? q : trash;
+    uint64_t acc = 0;
+    uint32_t fill = 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint64_t row = pack_row_dot(v[2 * r] - m4, v[2 * r + 1] - m4, d, w_lo, w_hi, is8);
-        uint64_t word;
-        if (fn.push(row, 8u * d, word)) { pay[swzq8(q)] = word; q++; }
+        const uint64_t merged = acc | (row << fill);
+        pay[swzq8(qq)] = merged;
+        const uint32_t nf = fill + nb;
+        const bool emit = nf >= 64u;
+        const uint64_t spill = (row >> 1) >> (63u - fill);   // the bits of row beyond the word (0 when fill == 0)
+        acc = emit ? spill : merged;
+        fill = nf & 63u;
+        qq += emit ? 1u : 0u;
     }
 }
 
@@ -745,8 +757,8 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
                 if (cur.hasA) pack_tile_d8(ca, mnA, pay, offA);
                 if (cur.hasB) pack_tile_d8(cb, mnB, pay, offB);
             } else {
-                pack_tile(ca, mnA, dA, pay, offA);
-                pack_tile(cb, mnB, dB, pay, offB);
+                pack_tile(ca, mnA, dA, pay, offA, kWaveWords + (uint32_t)lane);
+                pack_tile(cb, mnB, dB, pay, offB, kWaveWords + (uint32_t)lane);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -807,7 +819,7 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
 // Chunk ids are arrival tickets, so every chunk in front of a workgroup belongs to a workgroup that is already
 // running: no assumption about dispatch order or residency; the spin is bounded all the same.
 struct EncSharedSmall {
-    uint64_t pay[kEncWaves][kWaveWords];
+    uint64_t pay[kEncWaves][kWaveWords + 64];
     uint32_t tot[kEncWaves];
     uint32_t acc, chunk, pre[3];
 };
@@ -848,8 +860,8 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_small_kernel(EncParams 
             if (k.hasA) pack_tile_d8(ra, mnA, pay, offA);
             if (k.hasB) pack_tile_d8(rb, mnB, pay, offB);
         } else {
-            pack_tile(ra, mnA, dA, pay, offA);
-            pack_tile(rb, mnB, dB, pay, offB);
+            pack_tile(ra, mnA, dA, pay, offA, kWaveWords + (uint32_t)lane);
+            pack_tile(rb, mnB, dB, pay, offB, kWaveWords + (uint32_t)lane);
         }
     }
     // the chunk's prefixes: sum of the word counts in front of it, in its frame and in the launch

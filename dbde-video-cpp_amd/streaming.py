@@ -65,6 +65,8 @@ class RoundTripStream:
 
     def _batch_bytes(self, slot, n):
         """Compressed bytes of the batch in `slot`, read without touching the codec stream."""
+        if n == 0:
+            return 0
         with torch.cuda.stream(self.s_copy):
             self.s_copy.wait_event(self.ev_enc[slot])
             self.total_pinned[slot:slot + 1].copy_((self.offs[slot][n - 1:n] + self.sizes[slot][n - 1:n]), non_blocking=True)
@@ -90,9 +92,10 @@ class RoundTripStream:
             self.ev_gath[slot].record(self.s_comm)
         return nbytes, sum(sizes)
 
-    def run(self, first_frame, n_frames, world=1, rank=0):
+    def run(self, first_frame, n_frames, world=1, rank=0, rounds=None):
         """Returns a dict: frames, seconds (host wall, everything drained), packed bytes of this rank,
-        gathered bytes (root's view of every rank) when gathering."""
+        gathered bytes (root's view of every rank) when gathering.  `rounds`: gather rounds every rank takes
+        part in (the batch count of the LARGEST rank block; a rank with fewer batches posts empty ones)."""
         codec, W, H, B = self.codec, self.W, self.H, self.batch
         nb = (n_frames + B - 1) // B
         count = lambda k: min(B, n_frames - k * B)
@@ -125,6 +128,9 @@ class RoundTripStream:
         if self.gather:
             a, b = self._post_gather((nb - 1) % 2, count(nb - 1), world, rank)
             packed, gathered = packed + a, gathered + b
+            for _ in range(nb, rounds or nb):          # blocks differ by a frame: keep the collective calls in step
+                a, b = self._post_gather((nb - 1) % 2, 0, world, rank)
+                gathered += b
         torch.cuda.synchronize(self.dev)
         dt = time.perf_counter() - t0
         codec.sync()

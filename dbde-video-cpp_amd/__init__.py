@@ -43,6 +43,7 @@ C_ABI_SYMBOLS = [
     "dbde_hip_unpack_frame_header", "dbde_hip_unpack_video_header",
     "dbde_hip_timing_enable", "dbde_hip_timing_read",
     "dbde_hip_stream_handle", "dbde_hip_device_index",
+    "dbde16_hip_max_frame_bytes", "dbde16_hip_encode_frames", "dbde16_hip_decode_frames",
     "dbde_hip_writer_open", "dbde_hip_writer_put", "dbde_hip_writer_error", "dbde_hip_writer_close",
     "dbde_hip_reader_open", "dbde_hip_reader_next", "dbde_hip_reader_close",
 ]
@@ -143,6 +144,12 @@ def lib():
     L.dbde_hip_stream_handle.argtypes = [vp]
     L.dbde_hip_device_index.restype = i
     L.dbde_hip_device_index.argtypes = [vp]
+    L.dbde16_hip_max_frame_bytes.restype = sz
+    L.dbde16_hip_max_frame_bytes.argtypes = [i, i]
+    L.dbde16_hip_encode_frames.restype = i
+    L.dbde16_hip_encode_frames.argtypes = [vp, vp, i, i, i, u64, vp, sz, u64, vp, vp]
+    L.dbde16_hip_decode_frames.restype = i
+    L.dbde16_hip_decode_frames.argtypes = [vp, vp, sz, vp, i, i, i, vp, vp]
     L.dbde_hip_writer_open.restype = i
     L.dbde_hip_writer_open.argtypes = [vp, C.c_char_p, i, i, C.c_double, i, C.POINTER(vp)]
     L.dbde_hip_writer_put.restype = i
@@ -318,6 +325,25 @@ class Codec:
         """results tensor (n,4) int64 -> list of (u64s, index, elapsed_ns, consumed)."""
         r = results.cpu().numpy().view(np.uint64)
         return [(int(a) & 0xFFFFFFFF, int(b), int(c), int(d)) for a, b, c, d in r]
+
+    # ---- DBDE16 (higher-bit-depth extension, parity unpinned) ---------------------------------
+    def encode_frames16(self, images, W, H, n, out, out_offset, capacity, first_index=0, slot_stride=0):
+        """images: int16/uint16-sized device tensor of n*H*W pixels.  Returns (offsets, nbytes) int64 device tensors."""
+        offsets = torch.empty(n, dtype=torch.int64, device=self.device)
+        nbytes = torch.empty(n, dtype=torch.int64, device=self.device)
+        rc = self.L.dbde16_hip_encode_frames(self.h, images.data_ptr(), W, H, n, first_index, out.data_ptr() + out_offset,
+                                             capacity, slot_stride, offsets.data_ptr(), nbytes.data_ptr())
+        self._check(rc, "dbde16_hip_encode_frames")
+        return offsets, nbytes
+
+    def decode_frames16(self, stream, stream_offset, stream_bytes, offsets, W, H, n, images=None):
+        if images is None:
+            images = torch.empty((n, H, W), dtype=torch.int16, device=self.device)
+        results = torch.empty((n, 4), dtype=torch.int64, device=self.device)
+        rc = self.L.dbde16_hip_decode_frames(self.h, stream.data_ptr() + stream_offset, stream_bytes, offsets.data_ptr(),
+                                             W, H, n, images.data_ptr(), results.data_ptr())
+        self._check(rc, "dbde16_hip_decode_frames")
+        return images, results
 
     # ---- host-pointer API: the reference's functions -------------------------------------
     def pack_frame(self, index, image, W, H):

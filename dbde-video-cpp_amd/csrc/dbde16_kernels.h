@@ -1,0 +1,44 @@
+// dbde16_kernels.h -- launch interface of the DBDE16 kernels (dbde16_kernels.hip); see oracle/dbde16_oracle.c for
+// the format.  One tile per lane, 512 tiles per workgroup (the 8-bit decoder's chunk: its index kernels are shared).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dbde16 {
+
+constexpr uint32_t kChunkTiles16 = 512;
+
+struct Params16 {                   // encode
+    const uint16_t *images;         // n_frames * W*H pixels, pitch W
+    uint8_t *out;
+    uint64_t *frame_offsets;        // optional [n_frames]
+    uint64_t *frame_bytes;          // optional [n_frames]
+    uint64_t first_index;
+    uint64_t slot_stride;           // 0 = frames concatenated
+    uint64_t frame_pixels;
+    int W, H;
+    uint32_t w, h, T, chunks_per_frame;
+    // workspace
+    uint8_t *ws_depth;              // [n_frames * T]
+    uint16_t *ws_min;               // [n_frames * T]
+    uint32_t *chunk_words;          // [n_frames * cpf] totals, then exclusive in-frame offsets
+    uint32_t *frame_words;          // [n_frames]
+    uint64_t *frame_base;           // [n_frames] byte offset of each frame from `out`
+    uint32_t *arrivals;             // zero between launches
+};
+
+struct DecParams16 {
+    const uint8_t *stream;
+    const uint64_t *frame_offsets;
+    uint16_t *images;
+    const uint32_t *chunk_off;      // [n_frames][cpf + 1] from the index kernels
+    const uint32_t *frame_ok;
+    uint64_t frame_pixels;
+    int W, H;
+    uint32_t w, h, T, chunks_per_frame;
+};
+
+hipError_t launch_encode16(const Params16 &p, int n_frames, hipStream_t s);
+hipError_t launch_decode16(const DecParams16 &p, int n_frames, hipStream_t s);
+
+}  // namespace dbde16

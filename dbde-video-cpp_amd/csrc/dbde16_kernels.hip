@@ -1,0 +1,299 @@
+// dbde16_kernels.hip -- DBDE16 on MI355X (gfx950): the higher-bit-depth extension reference README.md:65 points at,
+// as specified in oracle/dbde16_oracle.c (U16 pixels, depth 0..16, U16 minima, nm = 2T).  PARITY UNPINNED: the
+// reference defines no such format; the kernels are checked against the DBDE16 oracle, which in turn agrees with
+// the pinned 8-bit oracle on 8-bit images.
+//
+// Correctness-first companion of dbde_kernels.hip, same decomposition, ONE tile per lane (a tile row is 8 pixels =
+// 16 bytes, so every image access is still one 16-byte access per row and lane):
+//   encode: enc16_stats   -- per tile min / max / depth, per-chunk word totals (512 tiles per workgroup)
+//           enc16_scan    -- chunk offsets inside each frame, frame bases (concatenated layout), I32 fields, header
+//           enc16_pack    -- re-reads the pixels (the format's dense packing needs the offsets first; the 8-bit
+//                            encoder's single-pass scanner machinery is not duplicated here), packs, stores
+//   decode: the 8-bit path's index kernels (IdxParams::min_bytes = 2) + dec16_kernel.
+// A tile row is the 8*d-bit integer at byte r*d of the tile payload, exactly as in the 8-bit format: rows are
+// assembled / taken apart as two 4-pixel halves of 4*d <= 64 bits.
+#include "dbde16_kernels.h"
+
+namespace dbde16 {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32x4_t __attribute__((aligned(1))) u32x4_unaligned;
+
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {   // DPP inclusive scan over the wave
+    uint32_t t = x;
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xF, 0xF, false);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xF, 0xF, false);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, false);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xF, false);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, false);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, false);
+    return t;
+}
+__device__ __forceinline__ void store_u32_bytes(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void store_u64_any(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+
+// One tile (possibly partial: clamp-to-edge = the format's constant padding) into 8 rows x 4 dwords (2 pixels each).
+__device__ __forceinline__ void load_tile16(const uint16_t *img, int W, int H, uint32_t ty, uint32_t tx, uint32_t (&v)[32]) {
+    const int x0 = 8 * (int)tx;
+    if (x0 + 8 <= W) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int yy = 8 * (int)ty + r;
+            yy = yy < H ? yy : H - 1;
+            const u32x4_t q = *reinterpret_cast<const u32x4_unaligned *>(img + (size_t)yy * (size_t)W + x0);
+            v[4 * r] = q[0]; v[4 * r + 1] = q[1]; v[4 * r + 2] = q[2]; v[4 * r + 3] = q[3];
+        }
+    } else {   // right-edge tile: pixel by pixel, the last valid one repeated
+        for (int r = 0; r < 8; r++) {
+            int yy = 8 * (int)ty + r;
+            yy = yy < H ? yy : H - 1;
+            for (int c = 0; c < 8; c += 2) {
+                const int xa = x0 + c < W ? x0 + c : W - 1, xb = x0 + c + 1 < W ? x0 + c + 1 : W - 1;
+                v[4 * r + c / 2] = (uint32_t)img[(size_t)yy * (size_t)W + xa] | ((uint32_t)img[(size_t)yy * (size_t)W + xb] << 16);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ void tile_minmax16(const uint32_t (&v)[32], uint32_t &mn, uint32_t &mx) {
+    uint32_t lo = v[0], hi = v[0];
+#pragma unroll
+    for (int i = 1; i < 32; i++) { lo = pk_min_u16(lo, v[i]); hi = pk_max_u16(hi, v[i]); }
+    mn = (lo & 0xFFFFu) < (lo >> 16) ? (lo & 0xFFFFu) : (lo >> 16);
+    mx = (hi & 0xFFFFu) > (hi >> 16) ? (hi & 0xFFFFu) : (hi >> 16);
+}
+__device__ __forceinline__ uint32_t depth_of(uint32_t range) { return range ? 32u - (uint32_t)__builtin_clz(range) : 0u; }
+
+struct Tile16 { uint32_t f, cf, t, ty, tx; bool has; };
+__device__ __forceinline__ Tile16 tile_of(const Params16 &p, uint32_t c, uint32_t tid) {
+    Tile16 k;
+    k.f = c / p.chunks_per_frame;
+    k.cf = c - k.f * p.chunks_per_frame;
+    k.t = k.cf * kChunkTiles16 + tid;
+    k.has = k.t < p.T;
+    const uint32_t t = k.has ? k.t : 0u;
+    k.ty = t / p.w;
+    k.tx = t - k.ty * p.w;
+    return k;
+}
+
+// ---- encode 1: statistics -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kChunkTiles16) void enc16_stats(Params16 p) {
+    __shared__ uint32_t s_tot[kChunkTiles16 / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const Tile16 k = tile_of(p, blockIdx.x, tid);
+    uint32_t v[32];
+    load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
+    uint32_t mn, mx;
+    tile_minmax16(v, mn, mx);
+    const uint32_t d = k.has ? depth_of(mx - mn) : 0u;
+    if (k.has) {
+        p.ws_depth[(size_t)k.f * p.T + k.t] = (uint8_t)d;
+        p.ws_min[(size_t)k.f * p.T + k.t] = (uint16_t)mn;
+    }
+    const uint32_t incl = wave_scan_incl(d);
+    if (lane == 63u) s_tot[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) tot += s_tot[q];
+        p.chunk_words[blockIdx.x] = tot;
+    }
+}
+
+// ---- encode 2: offsets.  One workgroup per frame scans its chunk totals; the last workgroup to finish (arrival
+// counter) turns the frame totals into frame bases for the concatenated layout. ----------------------------------
+__global__ __launch_bounds__(256) void enc16_scan(Params16 p) {
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_last;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t cpf = p.chunks_per_frame;
+    uint32_t *cw = p.chunk_words + (size_t)f * cpf;
+    const uint32_t seg = (cpf + 255u) / 256u, k0 = tid * seg;
+    uint32_t local = 0;
+    for (uint32_t k = k0; k < k0 + seg && k < cpf; k++) local += cw[k];
+    const uint32_t incl = wave_scan_incl(local);
+    if (lane == 63u) s_part[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t q = 0; q < 4; q++) { base += q < wave ? s_part[q] : 0u; total += s_part[q]; }
+    uint32_t run = base + incl - local;
+    for (uint32_t k = k0; k < k0 + seg && k < cpf; k++) { const uint32_t v = cw[k]; cw[k] = run; run += v; }   // -> exclusive offsets
+    if (tid == 0) {
+        p.frame_words[f] = total;
+        __threadfence();
+        s_last = atomicAdd(p.arrivals, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {   // frame bases: a few thousand frames at most, one lane
+        const uint64_t meta = 32ull + 3ull * p.T;
+        uint64_t at = 0;
+        for (uint32_t g = 0; g < gridDim.x; g++) {
+            const uint32_t words = __hip_atomic_load(&p.frame_words[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t fbase = p.slot_stride ? (uint64_t)g * p.slot_stride : at;
+            p.frame_base[g] = fbase;
+            if (p.frame_offsets) p.frame_offsets[g] = fbase;
+            if (p.frame_bytes) p.frame_bytes[g] = meta + 8ull * words;
+            at += meta + 8ull * words;
+        }
+        *p.arrivals = 0;   // clean for the next launch
+    }
+}
+
+// ---- encode 3: pack ---------------------------------------------------------------------------------------------
+// Four pixels (two dwords, 16 bits each, already minus the minimum) -> the 4*d-bit integer p0 | p1<<d | p2<<2d | p3<<3d.
+__device__ __forceinline__ uint64_t pack4x16(uint32_t a, uint32_t b, uint32_t d) {
+    const uint64_t lo = (uint64_t)(a & 0xFFFFu) | ((uint64_t)(a >> 16) << d);
+    const uint64_t hi = (uint64_t)(b & 0xFFFFu) | ((uint64_t)(b >> 16) << d);
+    return lo | (hi << (2u * d));
+}
+
+__global__ __launch_bounds__(kChunkTiles16) void enc16_pack(Params16 p) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kChunkTiles16 * 16 + 64 * (kChunkTiles16 / 64)];   // 16 words per tile + trash words
+    __shared__ uint32_t s_tot[kChunkTiles16 / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const Tile16 k = tile_of(p, blockIdx.x, tid);
+    uint32_t v[32];
+    load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
+    const uint32_t d = k.has ? p.ws_depth[(size_t)k.f * p.T + k.t] : 0u;
+    const uint32_t mn = k.has ? p.ws_min[(size_t)k.f * p.T + k.t] : 0u;
+    const uint32_t incl = wave_scan_incl(d);
+    if (lane == 63u) s_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) { wbase += q < wave ? s_tot[q] : 0u; total += s_tot[q]; }
+    // straight-line funnel over 16 half rows of 4*d <= 64 bits (every half row stores the word it is filling)
+    const uint32_t mn2 = mn * 0x00010001u;   // every 16-bit half >= mn: no borrow crosses a half
+    const uint32_t nb = 4u * d;
+    uint32_t q = d ? wbase + incl - d : kChunkTiles16 * 16u + tid;   // word index in the chunk image (trash word without payload)
+    uint64_t acc = 0;
+    uint32_t fill = 0;
+#pragma unroll
+    for (int h = 0; h < 16; h++) {
+        const uint64_t bits = pack4x16(v[2 * h] - mn2, v[2 * h + 1] - mn2, d);
+        const uint64_t merged = acc | (bits << fill);
+        s_pay[q] = merged;
+        const uint32_t nf = fill + nb;
+        const bool emit = nf >= 64u;
+        acc = emit ? ((bits >> 1) >> (63u - fill)) : merged;
+        fill = nf & 63u;
+        q += emit ? 1u : 0u;
+    }
+    __syncthreads();
+    // metadata of this lane's tile, then the chunk's contiguous payload
+    const uint64_t meta = 32ull + 3ull * p.T;
+    uint8_t *fb = p.out + p.frame_base[k.f];
+    if (k.has) {
+        fb[24 + k.t] = (uint8_t)d;
+        uint8_t *m = fb + 28 + p.T + 2ull * k.t;
+        m[0] = (uint8_t)mn; m[1] = (uint8_t)(mn >> 8);
+    }
+    const uint32_t chunk_off = p.chunk_words[blockIdx.x];   // exclusive offset inside the frame (enc16_scan)
+    uint8_t *dst = fb + meta + 8ull * chunk_off;
+    for (uint32_t i = tid; i < total; i += kChunkTiles16) store_u64_any(dst + 8ull * i, s_pay[i]);
+    if (tid == 0 && k.cf == 0u) {   // frame header and the I32 fields (trap T1: elapsed travels as an F64; 0 here)
+        const uint64_t index = p.first_index + k.f;
+        store_u32_bytes(fb, 2u);
+        store_u64_any(fb + 4, index);
+        store_u64_any(fb + 12, 0ull);
+        store_u32_bytes(fb + 20, p.T);
+        store_u32_bytes(fb + 24 + p.T, 2u * p.T);
+        store_u32_bytes(fb + 28 + 3ull * p.T, p.frame_words[k.f]);
+    }
+}
+
+// ---- decode ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kChunkTiles16 * 128 + 32];
+    __shared__ uint32_t s_tot[kChunkTiles16 / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t c = blockIdx.x, f = c / p.chunks_per_frame, cf = c - f * p.chunks_per_frame;
+    if (!p.frame_ok[f]) return;   // rejected frame: image untouched
+    const uint8_t *fb = p.stream + p.frame_offsets[f];
+    const uint32_t *co = p.chunk_off + (size_t)f * (p.chunks_per_frame + 1u) + cf;
+    const uint32_t w_begin = co[0], words = co[1] - co[0];
+    const uint32_t t = cf * kChunkTiles16 + tid;
+    const bool has = t < p.T;
+    const uint8_t *src = fb + 32ull + 3ull * p.T + 8ull * w_begin;
+    for (uint32_t i = tid; i < words; i += kChunkTiles16) {   // the chunk's payload: one contiguous byte range
+        uint64_t w;
+        __builtin_memcpy(&w, src + 8ull * i, 8);
+        *reinterpret_cast<uint64_t *>(s_in + 8u * i) = w;
+    }
+    uint32_t d = 0, mn = 0;
+    if (has) {
+        d = fb[24 + t];
+        const uint8_t *m = fb + 28 + p.T + 2ull * t;
+        mn = (uint32_t)m[0] | ((uint32_t)m[1] << 8);
+    }
+    const uint32_t incl = wave_scan_incl(d);
+    if (lane == 63u) s_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) wbase += q < wave ? s_tot[q] : 0u;
+    if (!has) return;
+    const uint32_t byte0 = 8u * (wbase + incl - d);
+    const uint32_t ty = t / p.w, tx = t - ty * p.w;
+    const int x0 = 8 * (int)tx;
+    const uint64_t fmask = d >= 16u ? 0xFFFFull : ((1ull << d) - 1ull);
+    uint16_t *img = p.images + (size_t)f * p.frame_pixels;
+    // A row's 8*d bits start at byte r*d of the tile payload: two 64-bit windows, one per 4-pixel half (the second
+    // starts 4*d bits = d/2 bytes, and 4 bits when d is odd, later).  LDS takes 8-byte reads at any byte address
+    // (profiles/lds_unaligned_probe.hip); all sixteen are requested before the first is used.
+    uint64_t lo[8], hi[8];
+    {
+        const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)s_in + byte0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            asm volatile("ds_read_b64 %0, %1" : "=v"(lo[r]) : "v"(la + (uint32_t)r * d) : "memory");
+            asm volatile("ds_read_b64 %0, %1" : "=v"(hi[r]) : "v"(la + (uint32_t)r * d + (d >> 1)) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint64_t h2 = hi[r] >> ((d & 1u) * 4u);
+        uint32_t px[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            px[i] = ((uint32_t)((lo[r] >> (i * d)) & fmask) + mn) & 0xFFFFu;       // modulo 2^16, as the spec says
+            px[4 + i] = ((uint32_t)((h2 >> (i * d)) & fmask) + mn) & 0xFFFFu;
+        }
+        const int yy = 8 * (int)ty + r;
+        if (yy < p.H) {
+            uint16_t *row = img + (size_t)yy * (size_t)p.W + x0;
+            if (x0 + 8 <= p.W) {
+                u32x4_t o;
+                o[0] = px[0] | (px[1] << 16); o[1] = px[2] | (px[3] << 16); o[2] = px[4] | (px[5] << 16); o[3] = px[6] | (px[7] << 16);
+                *reinterpret_cast<u32x4_unaligned *>(row) = o;
+            } else {
+                for (int i = 0; i < 8; i++) if (x0 + i < p.W) row[i] = (uint16_t)px[i];
+            }
+        }
+    }
+}
+
+hipError_t launch_encode16(const Params16 &p, int n_frames, hipStream_t s) {
+    const uint32_t n_chunks = (uint32_t)n_frames * p.chunks_per_frame;
+    hipLaunchKernelGGL(enc16_stats, dim3(n_chunks), dim3(kChunkTiles16), 0, s, p);
+    hipLaunchKernelGGL(enc16_scan, dim3(n_frames), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(enc16_pack, dim3(n_chunks), dim3(kChunkTiles16), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode16(const DecParams16 &p, int n_frames, hipStream_t s) {
+    hipLaunchKernelGGL(dec16_kernel, dim3((uint32_t)n_frames * p.chunks_per_frame), dim3(kChunkTiles16), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace dbde16

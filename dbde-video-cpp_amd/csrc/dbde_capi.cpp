@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "dbde16_kernels.h"
 #include "dbde_kernels.h"
 
 using namespace dbde;
@@ -44,6 +45,9 @@ struct dbde_hip_ctx {
     // scan-ahead: a second stream so that the frame-to-frame walk of the NEXT batch runs beside the decode of this one
     hipStream_t scan_stream = nullptr;
     hipEvent_t scan_ev_main = nullptr, scan_ev_done = nullptr;
+    // DBDE16 encode workspace (per-tile depth / minimum, chunk and frame totals, frame bases, arrival counter)
+    uint8_t *w16 = nullptr;
+    size_t w16_bytes = 0;
     bool lb_clean = false;           // records and counters are all zero (small launches leave them so)
     // decode workspace
     uint32_t *chunk_off = nullptr;
@@ -191,6 +195,7 @@ void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     if (ctx->scan_stream) { (void)hipStreamSynchronize(ctx->scan_stream); (void)hipStreamDestroy(ctx->scan_stream); }
     if (ctx->scan_ev_main) (void)hipEventDestroy(ctx->scan_ev_main);
     if (ctx->scan_ev_done) (void)hipEventDestroy(ctx->scan_ev_done);
+    if (ctx->w16) (void)hipFree(ctx->w16);
     if (ctx->lb) (void)hipFree(ctx->lb);
     if (ctx->chunk_off) (void)hipFree(ctx->chunk_off);
     if (ctx->frame_ok) (void)hipFree(ctx->frame_ok);
@@ -367,6 +372,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
         ip.results = d_results;
         ip.T = g.T;
         ip.chunks_per_frame = dcpf;
+        ip.min_bytes = 1;
         ip.geom = dg;
         // Few frames: cut each frame into pieces so that the index pass fills the device too
         // (>= 4 chunks per piece, about 1024 workgroups in all); from 256 frames on, one workgroup per frame.
@@ -489,6 +495,108 @@ int dbde_hip_synth_frames(dbde_hip_ctx *ctx, int mode, uint64_t seed, uint64_t f
     if (n_frames == 0) return DBDE_HIP_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_synth(mode, seed, first_frame, n_frames, W, H, d_images, ctx->stream));
+    return DBDE_HIP_OK;
+}
+
+// ---- DBDE16: the higher-bit-depth extension (include/dbde_hip.h, oracle/dbde16_oracle.c) ----------------------
+
+size_t dbde16_hip_max_frame_bytes(int W, int H) {
+    Geometry g;
+    if (!geometry(W, H, g)) return 0;
+    return 20 + 12 + 131 * (size_t)g.T;
+}
+
+int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W, int H, int n_frames, uint64_t first_index,
+                             uint8_t *d_out, size_t out_capacity, uint64_t slot_stride, uint64_t *d_frame_offsets,
+                             uint64_t *d_frame_bytes) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    Geometry g;
+    if (!d_images || !d_out || n_frames < 0 || !geometry(W, H, g))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "encode16: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
+    if (n_frames == 0) return DBDE_HIP_OK;
+    const uint64_t maxf = 32ull + 131ull * g.T;
+    if (slot_stride ? (slot_stride < maxf || (uint64_t)(n_frames - 1) * slot_stride + maxf > out_capacity)
+                    : (uint64_t)n_frames * maxf > out_capacity)
+        return fail(ctx, DBDE_HIP_ERR_CAPACITY, "encode16: out_capacity (or slot_stride) below the worst case");
+    const uint32_t cpf = (g.T + dbde16::kChunkTiles16 - 1) / dbde16::kChunkTiles16;
+    if ((uint64_t)n_frames * cpf >= (1ull << 31) || (uint64_t)g.T * 16ull >= (1ull << 32))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "encode16: launch too large");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // workspace: [arrivals 16 B][frame_base 8n][frame_words 4n][chunk_words 4 n cpf][ws_min 2 n T][ws_depth n T]
+    const size_t n = (size_t)n_frames;
+    const size_t o_base = 16, o_fw = o_base + 8 * n, o_cw = o_fw + 4 * n, o_min = (o_cw + 4 * n * cpf + 15) & ~(size_t)15,
+                 o_dep = o_min + 2 * n * g.T, need = o_dep + n * g.T + 64;
+    const size_t had = ctx->w16_bytes;
+    int rc = grow(ctx, ctx->w16, ctx->w16_bytes, need, 1);
+    if (rc) return rc;
+    if (ctx->w16_bytes != had) HIP_TRY(ctx, hipMemsetAsync(ctx->w16, 0, 16, ctx->stream));   // the arrival counter keeps itself zero
+    dbde16::Params16 p;
+    p.images = d_images;
+    p.out = d_out;
+    p.frame_offsets = d_frame_offsets;
+    p.frame_bytes = d_frame_bytes;
+    p.first_index = first_index;
+    p.slot_stride = slot_stride;
+    p.frame_pixels = g.pixels;
+    p.W = W; p.H = H; p.w = g.w; p.h = g.h; p.T = g.T;
+    p.chunks_per_frame = cpf;
+    p.arrivals = reinterpret_cast<uint32_t *>(ctx->w16);
+    p.frame_base = reinterpret_cast<uint64_t *>(ctx->w16 + o_base);
+    p.frame_words = reinterpret_cast<uint32_t *>(ctx->w16 + o_fw);
+    p.chunk_words = reinterpret_cast<uint32_t *>(ctx->w16 + o_cw);
+    p.ws_min = reinterpret_cast<uint16_t *>(ctx->w16 + o_min);
+    p.ws_depth = ctx->w16 + o_dep;
+    span_begin(ctx, 0);
+    HIP_TRY(ctx, dbde16::launch_encode16(p, n_frames, ctx->stream));
+    span_end(ctx);
+    return DBDE_HIP_OK;
+}
+
+int dbde16_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, const uint64_t *d_frame_offsets,
+                             int W, int H, int n_frames, uint16_t *d_images, dbde_hip_frame_result *d_results) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    Geometry g;
+    if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "decode16: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
+    if (n_frames == 0) return DBDE_HIP_OK;
+    const DecGeom dg = dec_geometry(g.w, g.h, false);   // plain runs of 512 tiles
+    if (dg.cpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode16: frame too large");
+    const uint64_t n_chunks64 = (uint64_t)n_frames * dg.cpf;
+    if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode16: too many chunks in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64 + (size_t)n_frames, sizeof(uint32_t));
+    if (rc) return rc;
+    rc = grow(ctx, ctx->frame_ok, ctx->frame_ok_n, (size_t)n_frames, sizeof(uint32_t));
+    if (rc) return rc;
+    IdxParams ip;
+    ip.stream = d_stream;
+    ip.frame_offsets = d_frame_offsets;
+    ip.stream_bytes = stream_bytes;
+    ip.chunk_off = ctx->chunk_off;
+    ip.frame_ok = ctx->frame_ok;
+    ip.results = d_results;
+    ip.T = g.T;
+    ip.chunks_per_frame = dg.cpf;
+    ip.min_bytes = 2;        // U16 minima, depth <= 16, nm = 2T
+    ip.geom = dg;
+    ip.split = 1;            // one index workgroup per frame (the split form is a latency tool of the 8-bit path)
+    ip.frame_ctr = nullptr;
+    ip.frame_flag = nullptr;
+    span_begin(ctx, 1);
+    HIP_TRY(ctx, launch_decode_index(ip, n_frames, ctx->stream));
+    span_end(ctx);
+    dbde16::DecParams16 p;
+    p.stream = d_stream;
+    p.frame_offsets = d_frame_offsets;
+    p.images = d_images;
+    p.chunk_off = ctx->chunk_off;
+    p.frame_ok = ctx->frame_ok;
+    p.frame_pixels = g.pixels;
+    p.W = W; p.H = H; p.w = g.w; p.h = g.h; p.T = g.T;
+    p.chunks_per_frame = dg.cpf;
+    span_begin(ctx, 2);
+    HIP_TRY(ctx, dbde16::launch_decode16(p, n_frames, ctx->stream));
+    span_end(ctx);
     return DBDE_HIP_OK;
 }
 

@@ -112,6 +112,7 @@ struct IdxParams {
     uint32_t *frame_ok;             // out [n_frames]
     void *results;                  // optional dbde_hip_frame_result[n_frames]
     uint32_t T, chunks_per_frame;
+    uint32_t min_bytes;             // bytes per tile minimum: 1 = DBDE, 2 = DBDE16 (depth <= 8 * min_bytes, nm = T * min_bytes)
     DecGeom geom;                   // which tiles a chunk holds
     uint32_t split;                 // workgroups per frame (1 = decode_index_kernel, >1 = the split form)
     uint32_t *frame_ctr;            // [n_frames] arrivals per frame, zero between launches (split form)

@@ -103,6 +103,12 @@ __device__ __forceinline__ uint32_t swz16(uint32_t slot) { return slot ^ ((slot 
 __device__ __forceinline__ uint32_t swzq8(uint32_t q) { return (swz8(q >> 1) << 1) | (q & 1u); }
 __device__ __forceinline__ uint32_t swzq16(uint32_t q) { return (swz16(q >> 1) << 1) | (q & 1u); }
 
+// Any of the four depth bytes of x above the format's maximum (8, or 16 for DBDE16)?  Non-zero if so.
+__device__ __forceinline__ uint32_t depth_bytes_bad(uint32_t x, uint32_t min_bytes) {
+    return min_bytes == 1u ? ((x & 0xF0F0F0F0u) | (((x & 0x0F0F0F0Fu) + 0x77777777u) & 0x80808080u))
+                           : ((x & 0xE0E0E0E0u) | (((x & 0x1F1F1F1Fu) + 0x6F6F6F6Fu) & 0x80808080u));
+}
+
 // x86-64 `(uint64_t)double` as g++ compiles it (dbde_util.cpp:334): cvttsd2si below 2^63,
 // else cvttsd2si(v - 2^63) ^ 2^63; out-of-range and NaN give the "integer indefinite".
 __device__ __forceinline__ uint64_t f64_to_u64_x86(double v) {
@@ -951,7 +957,8 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t T = p.T, cpf = p.chunks_per_frame;
     const uint64_t off = p.frame_offsets[f];
-    const uint64_t need = 32ull + 2ull * T;   // header + metadata must lie inside the stream
+    const uint64_t meta_t = (1ull + p.min_bytes) * T;   // bytes of the depth and minimum arrays
+    const uint64_t need = 32ull + meta_t;   // header + metadata must lie inside the stream
     const bool in_range = off + need <= p.stream_bytes;
     const uint8_t *fb = p.stream + off;
 
@@ -999,7 +1006,7 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
                     mask &= keep <= 0 ? 0u : (keep >= 4 ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (int)(4 - keep))));
                 }
                 wv[j] &= mask;
-                bad_depth |= (wv[j] & 0xF0F0F0F0u) | ((wv[j] + 0x77777777u) & 0x80808080u);   // any byte > 8
+                bad_depth |= depth_bytes_bad(wv[j], p.min_bytes);
             }
             uint32_t k_first, k_last;
             if (incr && pos0 >= 0) {
@@ -1077,8 +1084,8 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
         if (ok) {
             const int32_t nb = (int32_t)load_u32_bytes(fb + 20);
             const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
-            const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
-            ok = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && !(s_flags & 1u);
+            const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + meta_t);
+            ok = nb == (int32_t)T && nm == (int32_t)(T * p.min_bytes) && n64 == (int32_t)total && !(s_flags & 1u);
             // the payload itself must also be inside the stream
             if (ok && off + need + 8ull * total > p.stream_bytes) ok = false;
             if (ok) consumed = need + 8ull * total;
@@ -1111,7 +1118,8 @@ __global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t T = p.T, cpf = p.chunks_per_frame;
     const uint64_t off = p.frame_offsets[f];
-    const uint64_t need = 32ull + 2ull * T;
+    const uint64_t meta_t = (1ull + p.min_bytes) * T;
+    const uint64_t need = 32ull + meta_t;
     const bool in_range = off + need <= p.stream_bytes;
     const uint8_t *fb = p.stream + off;
     uint32_t *co = p.chunk_off + (size_t)f * (cpf + 1u);
@@ -1134,7 +1142,7 @@ __global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
                     __builtin_memcpy(&x, darr + q, 4);
                     const uint32_t keep = c_hi - q;   // tiles of this chunk left
                     if (keep < 4u) x &= 0xFFFFFFFFu >> (8u * (4u - keep));
-                    bad |= (x & 0xF0F0F0F0u) | ((x + 0x77777777u) & 0x80808080u);   // any byte > 8
+                    bad |= depth_bytes_bad(x, p.min_bytes);
                     sum += __builtin_amdgcn_sad_u8(x, 0u, 0u);
                 }
             }
@@ -1191,8 +1199,8 @@ __global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
         if (ok) {
             const int32_t nb = (int32_t)load_u32_bytes(fb + 20);
             const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
-            const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
-            ok = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && !(flags & 1u);
+            const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + meta_t);
+            ok = nb == (int32_t)T && nm == (int32_t)(T * p.min_bytes) && n64 == (int32_t)total && !(flags & 1u);
             if (ok && off + need + 8ull * total > p.stream_bytes) ok = false;
             if (ok) consumed = need + 8ull * total;
         }

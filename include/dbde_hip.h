@@ -221,6 +221,23 @@ int dbde_hip_reader_next(dbde_hip_reader *r, uint8_t *d_images, int max_frames,
                          dbde_hip_frame_header *headers, int *n_out);
 void dbde_hip_reader_close(dbde_hip_reader *r);
 
+/* ---- DBDE16: higher-bit-depth frames (extension; PARITY UNPINNED) ------------------------------------------- */
+/* The reference's README notes that the minimum array "could expand size to handle higher bit depth images"
+ * (README.md:65) and defines nothing further.  DBDE16 is that expansion and nothing else -- U16 pixels (pitch W
+ * pixels), depth bytes 0..16, U16 little-endian minima, the second I32 = 2T (it is the BYTE count of the minimum
+ * array, README.md:63), payload and tiling rules unchanged; an 8-bit reader rejects such a frame on nm != T.
+ * Full specification: oracle/dbde16_oracle.c.  There is no reference behaviour to be bit-exact against: the kernels
+ * are checked against that oracle, which agrees with the pinned 8-bit oracle on images that fit 8 bits.
+ * Batch API on device buffers only, arguments as dbde_hip_encode_frames / dbde_hip_decode_frames (frame headers
+ * carry index first_index + f, elapsed 0); worst case per frame 20 + 12 + 131*T bytes. */
+size_t dbde16_hip_max_frame_bytes(int W, int H);
+int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W, int H, int n_frames,
+                             uint64_t first_index, uint8_t *d_out, size_t out_capacity,
+                             uint64_t slot_stride, uint64_t *d_frame_offsets, uint64_t *d_frame_bytes);
+int dbde16_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes,
+                             const uint64_t *d_frame_offsets, int W, int H, int n_frames,
+                             uint16_t *d_images, dbde_hip_frame_result *d_results);
+
 /* ---- kernel timing hook for bench.py ---------------------------------------------------- */
 /* When enabled, every encode / decode call brackets its kernels with HIP events on the
  * context's stream; dbde_hip_timing_read returns accumulated milliseconds and launch counts

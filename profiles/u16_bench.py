@@ -1,0 +1,40 @@
+"""DBDE16 throughput (extension, parity unpinned): n frames of 4096x3072 U16, per-tile random depth 0..16."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dbde_video_cpp_amd as dv
+
+W, H, n = 4096, 3072, 128
+codec = dv.Codec(0)
+g = torch.Generator(device="cuda").manual_seed(1)
+d = torch.randint(0, 17, (n, H // 8, W // 8), device="cuda", generator=g)
+dd = d.repeat_interleave(8, 1).repeat_interleave(8, 2)
+mask = (torch.ones_like(dd) << dd) - 1
+noise = torch.randint(0, 65536, (n, H, W), device="cuda", generator=g) & mask
+base = torch.randint(0, 32768, (n, H // 8, W // 8), device="cuda", generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+imgs = torch.minimum(base, 65535 - mask).add_(noise).to(torch.int32).to(torch.int16).contiguous()   # two's complement bits = the U16 pixels
+del d, dd, mask, noise, base
+cap = n * int(codec.L.dbde16_hip_max_frame_bytes(W, H))
+buf = torch.empty(32 + cap + 64, dtype=torch.uint8, device="cuda")
+out = torch.empty_like(imgs)
+for _ in range(2):
+    offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap)
+    codec.decode_frames16(buf, 32, cap, offs, W, H, n, images=out)
+codec.sync()
+assert torch.equal(out, imgs)
+packed = int(sizes.sum().item())
+codec.timing(True); codec.timing_read(reset=True)
+steps = 10
+t0 = time.perf_counter()
+for _ in range(steps):
+    offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap)
+    codec.decode_frames16(buf, 32, cap, offs, W, H, n, images=out)
+codec.sync()
+dt = (time.perf_counter() - t0) / steps
+tk = codec.timing_read()
+raw = n * W * H * 2
+enc, idx, dec = tk["encode"][0] / steps, tk["decode_index"][0] / steps, tk["decode"][0] / steps
+print(f"DBDE16 {n} x {W}x{H}: packed/raw {packed/raw:.3f}; encode (3 kernels, pixels read twice) {enc:.3f} ms = "
+      f"{(raw + packed)/enc/1e6:.0f} GB/s algorithmic ({(raw+packed)/enc/1e6/8000:.3f} of 8 TB/s); decode {dec:.3f} ms + index {idx:.3f} ms = "
+      f"{(raw + packed)/dec/1e6:.0f} GB/s ({(raw+packed)/dec/1e6/8000:.3f}); round trip {n/dt:.0f} frames/s")

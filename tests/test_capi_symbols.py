@@ -29,10 +29,10 @@ def _ensure_built():
 def test_header_and_export_list_agree():
     dv = _ensure_built()
     header = open(os.path.join(ROOT, "include", "dbde_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(dbde_hip_[a-z0-9_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(dbde(?:16)?_hip_[a-z0-9_]+)\s*\(", header)))
     assert declared == sorted(dv.C_ABI_SYMBOLS), set(declared) ^ set(dv.C_ABI_SYMBOLS)
     out = subprocess.run(["nm", "-D", "--defined-only", dv.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r" T (dbde_hip_[a-z0-9_]+)", out))
+    exported = set(re.findall(r" T (dbde(?:16)?_hip_[a-z0-9_]+)", out))
     assert set(declared) <= exported, set(declared) - exported
     lib = dv.lib()                          # loads (no GPU needed) and binds every symbol
     assert all(hasattr(lib, s) for s in declared)

@@ -143,6 +143,7 @@ class Bench:
         self.world, self.rank, self.local = world, rank, local
         self.dev = torch.device("cuda", local)
         self.codec = dv.Codec(local)
+        self.failed_exchange = False
 
     def fence(self):
         self.torch.cuda.synchronize(self.dev)
@@ -300,7 +301,14 @@ class Bench:
                 rts = RoundTripStream(self.codec, W, H, batch, source=source, source_stream=side, gather=g)
             self.fence()
             rounds = -(-(-(-n_total // self.world)) // batch)      # batches of the largest rank block
-            r = rts.run(lo, hi - lo, self.world, self.rank, rounds=rounds)
+            try:
+                r = rts.run(lo, hi - lo, self.world, self.rank, rounds=rounds)
+            except Exception as e:
+                if not g:
+                    raise
+                cols[name] = {"error": f"{type(e).__name__}: {e}"[:400]}   # the exchange failed: the other columns stand
+                self.failed_exchange = True
+                break
             t = torch.tensor([r["seconds"]], dtype=torch.float64, device=self.dev)
             if self.dist is not None:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -396,7 +404,9 @@ def main():
                 dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            import datetime
+            # collectives that hang abort after two minutes instead of ten: the gather leg below is guarded
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=120))
         assert dist.get_world_size() == args.gpus
     if args.dry_run:
         args.frames = args.frames or 16
@@ -413,6 +423,7 @@ def main():
     cfg = dict(CONFIGS[args.config])
     W, H = cfg["W"], cfg["H"]
     content = args.content or cfg["content"]
+    gather_failed = False
     gather_mode = None if (dist is None or args.no_gather) else ("host" if rehearsal and not rehearsal_nccl else "nccl")
 
     line = {"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "unit": "frames/s",
@@ -425,7 +436,8 @@ def main():
         # ---- the 10,000-frame stream: strong scaling over frame blocks, streaming driver -------------------
         n_total = args.frames or cfg["frames"]
         cols, (lo, hi) = b.stream(W, H, n_total, args.batch, content, gather_mode)
-        head = cols.get("with_gather", cols["kernels_only"])
+        head = cols["with_gather"] if "frames_per_s" in cols.get("with_gather", {}) else cols["kernels_only"]
+        gather_failed = b.failed_exchange
         line.update({"value": head["frames_per_s"], "raw_pixel_GBps": round(head["frames_per_s"] * W * H / 1e9, 1),
                      "ms_per_step": round(head["seconds"] / max(head["batches_per_rank"], 1) * 1e3, 4),
                      "steps": head["batches_per_rank"], "warmup": 0, "scaling": "strong",
@@ -481,12 +493,19 @@ def main():
                     line["configs"][str(k)] = strip(b.case(c["W"], c["H"], c["frames"], c["content"], c["layout"], sub_steps, 2))
                     line["configs"][str(k)]["workload"] = c["name"]
         # ---- gather pipeline (N > 1): batch k's compressed bytes travel while batch k+1 is encoded -------------
+        # (the headline and the contents above are complete at this point: whatever happens in the exchange leg --
+        #  it is the one part that has only ever run over gloo -- the line still carries them)
         if gather_mode and not args.only:
-            cols, _ = b.stream(W, H, world * 4 * min(B, 256), min(B, 256), content, gather_mode)
-            line["gather"] = {"kernels_only": cols["kernels_only"], "with_gather": cols["with_gather"],
-                              "note": "streaming driver, 4 batches per rank: variable-length gather of each batch's "
-                                      "compressed bytes to rank 0 (RCCL send/recv) overlapped with the next batch's "
-                                      "encode+decode; root ingress over xGMI bounds the second column"}
+            try:
+                cols, _ = b.stream(W, H, world * 4 * min(B, 256), min(B, 256), content, gather_mode)
+                gather_failed = b.failed_exchange
+                line["gather"] = {"kernels_only": cols["kernels_only"], "with_gather": cols["with_gather"],
+                                  "note": "streaming driver, 4 batches per rank: variable-length gather of each batch's "
+                                          "compressed bytes to rank 0 (RCCL send/recv) overlapped with the next batch's "
+                                          "encode+decode; root ingress over xGMI bounds the second column"}
+            except Exception as e:   # reported, not fatal: `value` does not depend on it
+                line["gather"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                gather_failed = True
         if rank == 0 and world == 1 and not args.no_single and not args.only:
             line["single_frame"] = b.single_frame(4096, 3072, "noise8")
             line["single_frame"]["mixed_us_per_round_trip"] = b.single_frame(4096, 3072, "mixed")["us_per_round_trip"]
@@ -498,6 +517,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(mk, 4096, 3072)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        if gather_failed:    # the communicator may be unusable: leave without the farewell collective
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 

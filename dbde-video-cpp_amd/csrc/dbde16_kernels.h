@@ -1,12 +1,13 @@
 // dbde16_kernels.h -- launch interface of the DBDE16 kernels (dbde16_kernels.hip); see oracle/dbde16_oracle.c for
-// the format.  One tile per lane, 512 tiles per workgroup (the 8-bit decoder's chunk: its index kernels are shared).
+// the format.  One tile per lane, 256 tiles per workgroup (32 KB of worst-case payload in LDS: four workgroups per CU);
+// the 8-bit decoder's index kernels are shared (DecGeom::ct = 256).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace dbde16 {
 
-constexpr uint32_t kChunkTiles16 = 512;
+constexpr uint32_t kChunkTiles16 = 256;
 
 struct Params16 {                   // encode
     const uint16_t *images;         // n_frames * W*H pixels, pitch W
@@ -29,6 +30,7 @@ struct Params16 {                   // encode
 
 struct DecParams16 {
     const uint8_t *stream;
+    uint64_t stream_bytes;          // readable extent of stream
     const uint64_t *frame_offsets;
     uint16_t *images;
     const uint32_t *chunk_off;      // [n_frames][cpf + 1] from the index kernels

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kChunkTiles16) void enc16_pack(Params16 p) {
 
 // ---- decode ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kChunkTiles16 * 128 + 32];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kChunkTiles16 * 128 + 48];
     __shared__ uint32_t s_tot[kChunkTiles16 / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t c = blockIdx.x, f = c / p.chunks_per_frame, cf = c - f * p.chunks_per_frame;
@@ -224,11 +224,24 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     const uint32_t w_begin = co[0], words = co[1] - co[0];
     const uint32_t t = cf * kChunkTiles16 + tid;
     const bool has = t < p.T;
+    // the chunk's payload: one contiguous byte range, fetched as aligned 16-byte pieces (source aligned down; the
+    // first tile's bytes then start `shift` bytes into the image; frames are at least 8 bytes into any buffer)
     const uint8_t *src = fb + 32ull + 3ull * p.T + 8ull * w_begin;
-    for (uint32_t i = tid; i < words; i += kChunkTiles16) {   // the chunk's payload: one contiguous byte range
-        uint64_t w;
-        __builtin_memcpy(&w, src + 8ull * i, 8);
-        *reinterpret_cast<uint64_t *>(s_in + 8u * i) = w;
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+    const uint8_t *asrc = src - shift;
+    const uint32_t n16 = (shift + 8u * words + 15u) >> 4;
+    for (uint32_t i = tid; i < n16; i += kChunkTiles16) {
+        u32x4_t q;
+        if (asrc + 16ull * (i + 1u) <= p.stream + p.stream_bytes) q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(asrc + 16ull * i));
+        else {   // the piece would cross the end of the readable extent: byte by byte
+            uint32_t wq[4] = {0, 0, 0, 0};
+            for (uint32_t b = 0; b < 16u; b++) {
+                const uint8_t *s1 = asrc + 16ull * i + b;
+                if (s1 < p.stream + p.stream_bytes) wq[b >> 2] |= (uint32_t)*s1 << (8u * (b & 3u));
+            }
+            q[0] = wq[0]; q[1] = wq[1]; q[2] = wq[2]; q[3] = wq[3];
+        }
+        *reinterpret_cast<u32x4_t *>(s_in + 16u * i) = q;
     }
     uint32_t d = 0, mn = 0;
     if (has) {
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     uint32_t wbase = 0;
     for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) wbase += q < wave ? s_tot[q] : 0u;
     if (!has) return;
-    const uint32_t byte0 = 8u * (wbase + incl - d);
+    const uint32_t byte0 = shift + 8u * (wbase + incl - d);
     const uint32_t ty = t / p.w, tx = t - ty * p.w;
     const int x0 = 8 * (int)tx;
     const uint64_t fmask = d >= 16u ? 0xFFFFull : ((1ull << d) - 1ull);

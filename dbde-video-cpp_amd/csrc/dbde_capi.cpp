@@ -559,7 +559,7 @@ int dbde16_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t 
     if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
         return fail(ctx, DBDE_HIP_ERR_ARG, "decode16: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
-    const DecGeom dg = dec_geometry(g.w, g.h, false);   // plain runs of 512 tiles
+    const DecGeom dg = dec_geometry(g.w, g.h, false, dbde16::kChunkTiles16);   // plain runs of 256 tiles
     if (dg.cpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode16: frame too large");
     const uint64_t n_chunks64 = (uint64_t)n_frames * dg.cpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode16: too many chunks in one call");
@@ -587,6 +587,7 @@ int dbde16_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t 
     span_end(ctx);
     dbde16::DecParams16 p;
     p.stream = d_stream;
+    p.stream_bytes = stream_bytes;
     p.frame_offsets = d_frame_offsets;
     p.images = d_images;
     p.chunk_off = ctx->chunk_off;

@@ -25,11 +25,11 @@ struct DecGeom {
 };
 // row_aligned = false: plain runs of 512 consecutive tiles (a workgroup's time is nearly independent of how
 // many of its 512 tile slots are used, so full chunks win wherever alignment with the image buys nothing).
-__host__ __device__ inline DecGeom dec_geometry(uint32_t w, uint32_t h, bool row_aligned) {
+__host__ __device__ inline DecGeom dec_geometry(uint32_t w, uint32_t h, bool row_aligned, uint32_t plain_ct = kChunkTiles) {
     DecGeom g;
     g.w = w; g.h = h; g.T = w * h;
     if (!row_aligned) {
-        g.ct = kChunkTiles; g.pieces = 1u; g.cpf = (g.T + kChunkTiles - 1u) / kChunkTiles;
+        g.ct = plain_ct; g.pieces = 1u; g.cpf = (g.T + plain_ct - 1u) / plain_ct;
     } else if (w <= kChunkTiles) {
         uint32_t rows = kChunkTiles / w;   // the staged image, 8 * rows * W <= 64 * rows * w bytes, fits 32 KiB
         if (rows < 1u) rows = 1u;

@@ -12,8 +12,7 @@ steps between barriers.  B*W*H is far beyond the 256 MiB Infinity Cache, so ever
 The same run then times, with the same method (HIP events on the codec's stream + host wall clock),
   contents : mixed (depths 0..8 uniform: the path that really bit-packs) and smooth, same shape
   configs  : "3" 1000 frames of 2048x2048 mixed as ONE concatenated stream, decoded as a .dbde reader would:
-                 in four batches from the offsets the device stream scanner finds, the walk of batch b+1
-                 (dbde_hip_scan_ahead, second stream) beside the decode of batch b;
+                 from the offsets the device stream scanner finds (dbde_hip_index_stream_async);
              "4" 1921x1081 mixed (every row unaligned, edge tiles on two sides: constant-pad path)
   single_frame : configs[1] literally, one frame per encode+decode call
   cpu_baseline : the reference (oracle/_ref) on ALL host cores
@@ -168,27 +167,18 @@ class Bench:
         packed_bytes = [0]
         found = torch.empty(B, dtype=torch.int64, device=self.dev) if scan else None
 
-        nb = 8 if scan and B % 8 == 0 else 1      # a reader walks the stream a batch at a time
-        per = B // nb
-        cursor = torch.zeros(1, dtype=torch.int64, device=self.dev) if scan else None
-        counts = torch.zeros(nb, dtype=torch.int32, device=self.dev) if scan else None
+        count = torch.zeros(1, dtype=torch.int32, device=self.dev) if scan else None
 
         def step():
             codec.encode_frames(imgs, W, H, B, buf, lead, cap, first_index=rank * B, offsets=offs, nbytes=sizes,
                                 slot_stride=slot)
             if scan:
-                # a reader's view: only the bytes and their total length are known.  The frame-to-frame walk of
-                # batch b+1 (second stream) runs beside the decode of batch b (dbde_hip_scan_ahead / _join)
+                # a reader's view: only the bytes and their total length are known.  The device finds the frame
+                # starts (dbde_hip_index_stream_async: the speculative segment-parallel walk) and the decode,
+                # enqueued behind it, takes its offsets from there
                 total = packed_bytes[0] or cap
-                cursor.zero_()
-                codec.scan_ahead(buf, lead, total, W, H, per, cursor, found[0:per], counts[0:1])
-                for b in range(nb):
-                    codec.scan_join()
-                    if b + 1 < nb:
-                        codec.scan_ahead(buf, lead, total, W, H, per, cursor, found[(b + 1) * per:(b + 2) * per],
-                                         counts[b + 1:b + 2])
-                    codec.decode_frames(buf, lead, total, found[b * per:(b + 1) * per], W, H, per,
-                                        images=out[b * per:(b + 1) * per], results=res[b * per:(b + 1) * per])
+                codec.index_stream_async(buf, lead, total, W, H, B, found, count)
+                codec.decode_frames(buf, lead, total, found, W, H, B, images=out, results=res)
             else:
                 codec.decode_frames(buf, lead, cap, offs, W, H, B, images=out, results=res)
 
@@ -203,7 +193,7 @@ class Bench:
             assert torch.equal(out, imgs), f"round trip mismatch ({W}x{H} {content} {layout})"
             if scan:
                 assert torch.equal(found, offs), "stream scanner offsets differ from the encoder's"
-                assert bool((counts == per).all()), "stream scanner lost frames"
+                assert int(count.item()) == B, "stream scanner lost frames"
         packed = int(sizes.sum().item())
 
         codec.timing(True)
@@ -239,9 +229,8 @@ class Bench:
              "identical": bool(check)}
         if scan:
             r["decode"]["scan_ms"] = round(scan_ms, 4)
-            r["decode"]["batches"] = nb
-            r["decode"]["note"] = ("reader pipeline: the walk of batch b+1 runs on a second stream beside the decode of "
-                                   "batch b; scan_ms is the walks' own time, mostly hidden; round_trip_frac is wall time")
+            r["decode"]["note"] = ("frame starts found on the device (speculative segment-parallel walk, exact by "
+                                   "construction), then one decode launch; scan_ms is inside the step")
         r["_dt_max"], r["_packed"] = dt_max, packed
         del imgs, buf, out
         return r

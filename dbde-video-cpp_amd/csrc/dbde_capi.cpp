@@ -45,6 +45,9 @@ struct dbde_hip_ctx {
     // scan-ahead: a second stream so that the frame-to-frame walk of the NEXT batch runs beside the decode of this one
     hipStream_t scan_stream = nullptr;
     hipEvent_t scan_ev_main = nullptr, scan_ev_done = nullptr;
+    // speculative stream walk: temporary position lists of the segments
+    uint8_t *scan_ws = nullptr;
+    size_t scan_ws_bytes = 0;
     // DBDE16 encode workspace (per-tile depth / minimum, chunk and frame totals, frame bases, arrival counter)
     uint8_t *w16 = nullptr;
     size_t w16_bytes = 0;
@@ -195,6 +198,7 @@ void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     if (ctx->scan_stream) { (void)hipStreamSynchronize(ctx->scan_stream); (void)hipStreamDestroy(ctx->scan_stream); }
     if (ctx->scan_ev_main) (void)hipEventDestroy(ctx->scan_ev_main);
     if (ctx->scan_ev_done) (void)hipEventDestroy(ctx->scan_ev_done);
+    if (ctx->scan_ws) (void)hipFree(ctx->scan_ws);
     if (ctx->w16) (void)hipFree(ctx->w16);
     if (ctx->lb) (void)hipFree(ctx->lb);
     if (ctx->chunk_off) (void)hipFree(ctx->chunk_off);
@@ -429,8 +433,38 @@ int dbde_hip_index_stream_async(dbde_hip_ctx *ctx, const uint8_t *d_stream, size
     if (!d_stream || !d_frame_offsets || !d_n_found || max_frames < 0 || !geometry(W, H, g))
         return fail(ctx, DBDE_HIP_ERR_ARG, "index_stream: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // Long streams are walked speculatively in up to 16 segments at once (scan_spec_kernel: exact by construction,
+    // the plain hop-by-hop walk is what it falls back to); short ones hop by hop.
+    const uint64_t maxlen = 32ull + 66ull * g.T, meta = 32ull + 2ull * g.T;
+    uint64_t n_seg = stream_bytes / (2 * maxlen);
+    if (n_seg > 16) n_seg = 16;   // the signature searches (one maximal frame each, at worst) are the cost: few, wide segments (measured: 8-16)
     span_begin(ctx, 3);
-    HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, nullptr, ctx->stream));
+    if (n_seg >= 2 && max_frames > 0) {
+        ScanParams sp;
+        sp.stream = d_stream;
+        sp.stream_bytes = stream_bytes;
+        sp.T = g.T;
+        sp.gran = g.T % 4 == 0 ? 8u : (g.T % 2 == 0 ? 4u : 2u);   // frame lengths 32 + 2T + 8 n64 are multiples of this
+        sp.seg_bytes = (stream_bytes + n_seg - 1) / n_seg;
+        sp.seg_cap = (uint32_t)(sp.seg_bytes / meta + 3);
+        // workspace: [found 8 x 64][arrive 4 x 64] (kept zero by the kernel) | lists | start, end, count, ended
+        const size_t fixed = 64 * 8 + 64 * 4, lists = (size_t)n_seg * sp.seg_cap * 8, need = fixed + lists + n_seg * 32 + 64;
+        const size_t had = ctx->scan_ws_bytes;
+        int rc = grow(ctx, ctx->scan_ws, ctx->scan_ws_bytes, need, 1);
+        if (rc) return rc;
+        if (ctx->scan_ws_bytes != had) HIP_TRY(ctx, hipMemsetAsync(ctx->scan_ws, 0, fixed, ctx->stream));
+        sp.seg_found_inv = reinterpret_cast<unsigned long long *>(ctx->scan_ws);
+        sp.seg_arrive = reinterpret_cast<uint32_t *>(ctx->scan_ws + 64 * 8);
+        sp.seg_pos = reinterpret_cast<uint64_t *>(ctx->scan_ws + fixed);
+        sp.seg_start = reinterpret_cast<uint64_t *>(ctx->scan_ws + fixed + lists);
+        sp.seg_end = sp.seg_start + n_seg;
+        sp.seg_count = reinterpret_cast<uint32_t *>(sp.seg_end + n_seg);
+        sp.seg_ended = sp.seg_count + n_seg;
+        sp.wg_per_seg = 4;                          // workgroups sharing a segment's signature search (measured: 1-4)
+        HIP_TRY(ctx, launch_scan_spec(sp, (uint32_t)n_seg, max_frames, d_frame_offsets, d_n_found, ctx->stream));
+    } else {
+        HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, nullptr, ctx->stream));
+    }
     span_end(ctx);
     return DBDE_HIP_OK;
 }

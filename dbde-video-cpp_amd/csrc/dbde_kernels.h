@@ -141,6 +141,25 @@ hipError_t launch_synth(int mode, uint64_t seed, uint64_t first_frame, int n_fra
 // Serial frame-to-frame hop over a concatenated stream (one wave); see dbde_hip_index_stream.
 hipError_t launch_scan_stream(const uint8_t *stream, uint64_t stream_bytes, uint32_t T, int max_frames,
                               uint64_t *d_offsets, uint32_t *d_count, uint64_t *d_cursor, hipStream_t s);
+// Speculative parallel walk (see scan_spec_kernel): the stream in n_seg <= kMaxScanSegments segments, temporary
+// position lists.
+constexpr uint32_t kMaxScanSegments = 64;
+struct ScanParams {
+    const uint8_t *stream;
+    uint64_t stream_bytes;
+    uint32_t T;
+    uint32_t gran;                 // frame starts are multiples of this many bytes from the stream's first byte
+    uint64_t seg_bytes;            // segment j covers [j * seg_bytes, (j + 1) * seg_bytes)
+    uint32_t seg_cap;              // entries per temporary list
+    uint64_t *seg_pos;             // [n_seg][seg_cap]
+    uint64_t *seg_start, *seg_end; // [n_seg] where a segment's walk began / the first frame start past the segment
+    uint32_t *seg_count, *seg_ended;
+    uint32_t wg_per_seg;           // workgroups that share a segment's signature search
+    unsigned long long *seg_found_inv;   // [n_seg] complement of the best match so far; zero between calls
+    uint32_t *seg_arrive;          // [n_seg] zero between calls
+};
+hipError_t launch_scan_spec(const ScanParams &p, uint32_t n_seg, int max_frames, uint64_t *d_offsets, uint32_t *d_count,
+                            hipStream_t s);
 // Maximum chunks_per_frame the decode index kernel can hold in LDS.
 constexpr uint32_t kMaxChunksPerFrame = 32768;
 

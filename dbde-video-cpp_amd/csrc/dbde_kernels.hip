@@ -1700,6 +1700,143 @@ hipError_t launch_scan_stream(const uint8_t *stream, uint64_t stream_bytes, uint
 }
 
 // ---------------------------------------------------------------------------------------
+// stream scanner, speculative form
+// ---------------------------------------------------------------------------------------
+// The walk is a chain of dependent HBM reads (0.4 us per frame alone, 1 us beside other traffic): 1000 frames cost
+// as much as decoding them.  But next(p) = p + 32 + 2T + 8 * n64(p) is a function of the bytes at p alone, so the
+// continuation of the chain from ANY true frame start is what the exact walk would compute there.  The stream is cut
+// into K segments; workgroup j looks for the first position at or after its segment's first byte that LOOKS like a
+// frame start (u32 2 | ... | u32 T at +20 | u32 T at +24+T -- the fields dbde_unpack_frame_header / dbde_unpack_image
+// check, dbde_util.cpp:295-300,335) and walks from there to the first frame start at or past the next segment.  All K
+// walks run at once.  Nothing is trusted: the stitch pass follows the exact chain from byte 0 and accepts segment
+// j only if the chain ARRIVES at the very position that segment started from (then its positions are the exact
+// walk's); a segment that was fooled by payload bytes is simply never arrived at, and the exact walk goes on hop by
+// hop until it meets the next segment start that it does arrive at.  Exact by construction, K-fold shorter in the
+// usual case.
+__device__ __forceinline__ uint32_t ld_u32_any(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// One exact hop: the frame at `off` (length in *len) if its fixed part and its payload lie inside the stream.
+__device__ __forceinline__ bool frame_at(const uint8_t *stream, uint64_t stream_bytes, uint64_t meta, uint32_t T, uint64_t off, uint64_t *len) {
+    if (off + meta > stream_bytes) return false;
+    const uint32_t n64 = ld_u32_any(stream + off + 28 + 2ull * T);
+    *len = meta + 8ull * n64;
+    return (int32_t)n64 >= 0 && off + *len <= stream_bytes;
+}
+
+__global__ __launch_bounds__(1024) void scan_spec_kernel(ScanParams p) {
+    __shared__ uint32_t s_last;
+    const uint32_t M = p.wg_per_seg, j = blockIdx.x / M, m = blockIdx.x - j * M, tid = threadIdx.x;
+    const uint32_t n_seg = gridDim.x / M;
+    const uint64_t meta = 32ull + 2ull * p.T;
+    const uint64_t q_lo = j == 0 ? 0ull : ((uint64_t)j * p.seg_bytes + p.gran - 1) / p.gran * p.gran;
+    const uint64_t q_hi = j + 1 == n_seg ? p.stream_bytes : (((uint64_t)(j + 1) * p.seg_bytes + p.gran - 1) / p.gran * p.gran);
+    uint64_t start = 0;
+    if (j != 0) {
+        // First position >= q_lo that carries the three fields of a frame start.  The segment's M workgroups take
+        // the candidate rounds in turn; the best match so far lives in a device word as its COMPLEMENT (atomicMax on
+        // a zero-initialised word = min of the positions); a workgroup stops once it is past it (it only moves
+        // down, so nothing below the final minimum is ever skipped).  The last workgroup to arrive walks.
+        const uint64_t limit = q_lo + 32ull + 66ull * p.T < p.stream_bytes ? q_lo + 32ull + 66ull * p.T : p.stream_bytes;   // a frame starts within one maximal frame
+        const uint64_t round_bytes = 16384ull * p.gran;
+        for (uint64_t base = q_lo + m * round_bytes; base < limit; base += M * round_bytes) {
+            if (base > ~__hip_atomic_load(&p.seg_found_inv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            uint32_t w[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) {
+                const uint64_t c = base + ((uint64_t)k * 1024u + tid) * p.gran;
+                w[k] = c + meta <= p.stream_bytes ? ld_u32_any(p.stream + c) : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) {
+                if (w[k] == 2u) {
+                    const uint64_t c = base + ((uint64_t)k * 1024u + tid) * p.gran;
+                    if (ld_u32_any(p.stream + c + 20) == p.T && ld_u32_any(p.stream + c + 24 + p.T) == p.T)
+                        atomicMax(&p.seg_found_inv[j], (unsigned long long)~c);
+                }
+            }
+        }
+        // the matches were published with device-scope atomics (performed at the memory side): once every wave has
+        // seen its own acknowledged, the arrival may be counted -- no fence (an agent-scope fence from 1024 threads
+        // of every workgroup cost more than the search)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&p.seg_arrive[j], 1u) == M - 1u ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) {
+            start = ~__hip_atomic_load(&p.seg_found_inv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.seg_found_inv[j] = 0;   // the workspace stays clean for the next call
+            p.seg_arrive[j] = 0;
+        }
+    } else if (m != 0) {
+        return;
+    }
+    if (tid != 0) return;
+    uint64_t *pos = p.seg_pos + (size_t)j * p.seg_cap;
+    uint32_t n = 0;
+    uint64_t off = start, len = 0;
+    uint32_t ended = 0;   // 1: the chain stops inside this segment (no further whole frame)
+    if (start != ~0ull) {
+        while (off < q_hi) {
+            if (!frame_at(p.stream, p.stream_bytes, meta, p.T, off, &len)) { ended = 1; break; }
+            if (n < p.seg_cap) pos[n] = off;
+            n++;
+            off += len;
+        }
+    }
+    p.seg_start[j] = start;
+    p.seg_end[j] = off;
+    p.seg_count[j] = n <= p.seg_cap ? n : ~0u;   // overflow of the temporary list: treat the segment as unusable
+    p.seg_ended[j] = ended;
+}
+
+__global__ __launch_bounds__(1024) void scan_stitch_kernel(ScanParams p, uint32_t n_seg, int max_frames, uint64_t *offsets, uint32_t *count) {
+    __shared__ unsigned long long s_start[kMaxScanSegments], s_end[kMaxScanSegments];
+    __shared__ uint32_t s_count[kMaxScanSegments], s_ended[kMaxScanSegments], s_base[kMaxScanSegments], s_use[kMaxScanSegments];
+    __shared__ uint32_t s_total;
+    const uint32_t tid = threadIdx.x;
+    if (tid < n_seg) { s_start[tid] = p.seg_start[tid]; s_end[tid] = p.seg_end[tid]; s_count[tid] = p.seg_count[tid]; s_ended[tid] = p.seg_ended[tid]; s_use[tid] = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        const uint64_t meta = 32ull + 2ull * p.T;
+        uint64_t cur = 0, len = 0;
+        uint32_t total = 0, j = 0;
+        bool done = false;
+        while (!done && total < (uint32_t)max_frames) {
+            // drop segments that can never be arrived at: already passed, found no start (~0), or overflowed their list
+            while (j < n_seg && (s_start[j] < cur || s_start[j] == ~0ull || s_count[j] == ~0u)) j++;
+            if (j < n_seg && s_start[j] == cur) {                        // the exact chain arrives at this segment's start
+                s_use[j] = 1; s_base[j] = total;
+                total += s_count[j];
+                cur = s_end[j];
+                done = s_ended[j] != 0u;
+                j++;
+            } else {                                                     // hop by hop until it does (or the stream ends)
+                if (!frame_at(p.stream, p.stream_bytes, meta, p.T, cur, &len)) { done = true; break; }
+                offsets[total++] = cur;
+                cur += len;
+            }
+        }
+        s_total = total < (uint32_t)max_frames ? total : (uint32_t)max_frames;
+        *count = s_total;
+    }
+    __syncthreads();
+    const uint32_t total = s_total;
+    for (uint32_t j = tid >> 6; j < n_seg; j += 16u) {   // a wave per segment: the copies of different segments overlap
+        if (!s_use[j]) continue;
+        const uint64_t *pos = p.seg_pos + (size_t)j * p.seg_cap;
+        for (uint32_t i = tid & 63u; i < s_count[j]; i += 64u)
+            if (s_base[j] + i < total) offsets[s_base[j] + i] = pos[i];
+    }
+}
+
+hipError_t launch_scan_spec(const ScanParams &p, uint32_t n_seg, int max_frames, uint64_t *d_offsets, uint32_t *d_count, hipStream_t s) {
+    hipLaunchKernelGGL(scan_spec_kernel, dim3(n_seg * p.wg_per_seg), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(scan_stitch_kernel, dim3(1), dim3(1024), 0, s, p, n_seg, max_frames, d_offsets, d_count);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // synthetic frames (same function as oracle/synth.c)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {

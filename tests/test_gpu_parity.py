@@ -238,6 +238,45 @@ def test_index_stream(codec):
     assert torch.equal(back, imgs)
 
 
+def test_index_stream_speculative_walk(codec, oracle):
+    """Long streams are walked in up to 64 segments at once, each from a position that LOOKS like a frame start, and
+    stitched only where the exact chain arrives (scan_spec_kernel).  Offsets must equal the encoder's for honest
+    streams, for tiny frames (many per segment), for frames larger than a segment, for a truncated tail, for a
+    max_frames cut -- and for a stream salted with byte patterns that look exactly like frame starts."""
+    import torch
+    for (W, H, n, mode) in [(200, 123, 300, "mixed"), (10, 10, 5000, "smooth"), (2048, 2048, 40, "mixed"),
+                            (1024, 768, 97, "noise8"), (64, 64, 1200, "flat")]:
+        imgs = codec.synth_frames(mode, SEED, 0, n, W, H)
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n)
+        total = int((offs[-1] + sizes[-1]).item())
+        found, cnt = codec.index_stream(buf, lead, total, W, H, n + 10)
+        assert cnt == n and torch.equal(found, offs), (W, H, n, mode)
+        found, cnt = codec.index_stream(buf, lead, total - 5, W, H, n + 10)      # truncated last frame
+        assert cnt == n - 1 and torch.equal(found, offs[:n - 1])
+        found, cnt = codec.index_stream(buf, lead, total, W, H, n // 2)          # the caller's limit
+        assert cnt == n // 2 and torch.equal(found, offs[:n // 2])
+    # decoys: all-noise frames whose payload is overwritten, at many positions, with the three fields of a frame
+    # start (2 | T | T).  The chain never lands on them, so they must change nothing.
+    W, H, n = 256, 256, 400
+    T = (W // 8) * (H // 8)
+    imgs = codec.synth_frames("noise8", SEED, 0, n, W, H)
+    frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n)
+    total = int((offs[-1] + sizes[-1]).item())
+    host = buf.cpu().numpy().copy()
+    o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+    rng = np.random.default_rng(3)
+    for f in range(n):
+        pay = lead + int(o[f]) + 32 + 2 * T              # payload of frame f: 64*T bytes of noise
+        for _ in range(3):
+            c = pay + 8 * int(rng.integers(0, (int(s[f]) - 32 - 2 * T - 32 - 2 * T) // 8 - 8))
+            host[c:c + 4] = np.frombuffer(np.uint32(2).tobytes(), np.uint8)
+            host[c + 20:c + 24] = np.frombuffer(np.uint32(T).tobytes(), np.uint8)
+            host[c + 24 + T:c + 28 + T] = np.frombuffer(np.uint32(T).tobytes(), np.uint8)
+    salted = torch.from_numpy(host).cuda()
+    found, cnt = codec.index_stream(salted, lead, total, W, H, n + 10)
+    assert cnt == n and torch.equal(found, offs)
+
+
 def test_scan_ahead_reader_pipeline(codec):
     """dbde_hip_scan_ahead / dbde_hip_scan_join: an un-indexed stream read a batch at a time, the walk of the next
     batch on the context's second stream beside the decode of the current one; uneven last batch, cursor carried

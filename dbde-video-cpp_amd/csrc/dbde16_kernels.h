@@ -19,13 +19,12 @@ struct Params16 {                   // encode
     uint64_t frame_pixels;
     int W, H;
     uint32_t w, h, T, chunks_per_frame;
-    // workspace
-    uint8_t *ws_depth;              // [n_frames * T]
-    uint16_t *ws_min;               // [n_frames * T]
-    uint32_t *chunk_words;          // [n_frames * cpf] totals, then exclusive in-frame offsets
-    uint32_t *frame_words;          // [n_frames]
-    uint64_t *frame_base;           // [n_frames] byte offset of each frame from `out`
-    uint32_t *arrivals;             // zero between launches
+    uint32_t n_frames;
+    // workspace, zeroed before every launch
+    unsigned long long *state;      // [n_frames * cpf] bit 63 = published, low 32 bits = payload words of the chunk
+    unsigned long long *frame_base; // [n_frames] bit 63 = known, rest = byte offset of the frame from `out` (concatenated layout)
+    uint32_t *ticket;               // chunk ids are arrival tickets
+    uint32_t *sticky;               // context-wide failure word, OR-ed on a look-back time-out
 };
 
 struct DecParams16 {

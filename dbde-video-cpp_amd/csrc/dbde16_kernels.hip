@@ -5,10 +5,8 @@
 //
 // Correctness-first companion of dbde_kernels.hip, same decomposition, ONE tile per lane (a tile row is 8 pixels =
 // 16 bytes, so every image access is still one 16-byte access per row and lane):
-//   encode: enc16_stats   -- per tile min / max / depth, per-chunk word totals (512 tiles per workgroup)
-//           enc16_scan    -- chunk offsets inside each frame, frame bases (concatenated layout), I32 fields, header
-//           enc16_pack    -- re-reads the pixels (the format's dense packing needs the offsets first; the 8-bit
-//                            encoder's single-pass scanner machinery is not duplicated here), packs, stores
+//   encode: enc16_kernel  -- one pass: a workgroup per 256-tile chunk reduces, publishes its word count, packs, and
+//                            finds its prefix by decoupled look-back over the records in front of it (ticket order)
 //   decode: the 8-bit path's index kernels (IdxParams::min_bytes = 2) + dec16_kernel.
 // A tile row is the 8*d-bit integer at byte r*d of the tile payload, exactly as in the 8-bit format: rows are
 // assembled / taken apart as two 4-pixel halves of 4*d <= 64 bits.
@@ -85,72 +83,17 @@ __device__ __forceinline__ Tile16 tile_of(const Params16 &p, uint32_t c, uint32_
     return k;
 }
 
-// ---- encode 1: statistics -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kChunkTiles16) void enc16_stats(Params16 p) {
-    __shared__ uint32_t s_tot[kChunkTiles16 / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const Tile16 k = tile_of(p, blockIdx.x, tid);
-    uint32_t v[32];
-    load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
-    uint32_t mn, mx;
-    tile_minmax16(v, mn, mx);
-    const uint32_t d = k.has ? depth_of(mx - mn) : 0u;
-    if (k.has) {
-        p.ws_depth[(size_t)k.f * p.T + k.t] = (uint8_t)d;
-        p.ws_min[(size_t)k.f * p.T + k.t] = (uint16_t)mn;
-    }
-    const uint32_t incl = wave_scan_incl(d);
-    if (lane == 63u) s_tot[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) tot += s_tot[q];
-        p.chunk_words[blockIdx.x] = tot;
-    }
-}
+// ---- encode: ONE pass ------------------------------------------------------------------------------------------
+// Workgroup = one chunk of 256 tiles, chunk id = arrival ticket (every chunk in front of a workgroup belongs to a
+// workgroup that is already running: no assumption about dispatch order).  Load, reduce, publish the chunk's word
+// count as an 8-byte record, pack into LDS while the record travels, then look back over the records in front of it
+// IN ITS FRAME (wave 0, 64 per poll) until one carries an inclusive prefix, upgrade its own record to inclusive, store.
+// Concatenated layout: the workgroup that holds a frame's last chunk knows the frame's byte count and publishes the
+// next frame's base; a chunk waits for its frame's base as it waits for its predecessors.  Records and bases are
+// zeroed before the launch (dbde16_hip_encode_frames).
+typedef unsigned long long u64a;
+constexpr u64a kReady = 1ull << 63, kInc = 1ull << 62;
 
-// ---- encode 2: offsets.  One workgroup per frame scans its chunk totals; the last workgroup to finish (arrival
-// counter) turns the frame totals into frame bases for the concatenated layout. ----------------------------------
-__global__ __launch_bounds__(256) void enc16_scan(Params16 p) {
-    __shared__ uint32_t s_part[4];
-    __shared__ uint32_t s_last;
-    const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t cpf = p.chunks_per_frame;
-    uint32_t *cw = p.chunk_words + (size_t)f * cpf;
-    const uint32_t seg = (cpf + 255u) / 256u, k0 = tid * seg;
-    uint32_t local = 0;
-    for (uint32_t k = k0; k < k0 + seg && k < cpf; k++) local += cw[k];
-    const uint32_t incl = wave_scan_incl(local);
-    if (lane == 63u) s_part[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-    for (uint32_t q = 0; q < 4; q++) { base += q < wave ? s_part[q] : 0u; total += s_part[q]; }
-    uint32_t run = base + incl - local;
-    for (uint32_t k = k0; k < k0 + seg && k < cpf; k++) { const uint32_t v = cw[k]; cw[k] = run; run += v; }   // -> exclusive offsets
-    if (tid == 0) {
-        p.frame_words[f] = total;
-        __threadfence();
-        s_last = atomicAdd(p.arrivals, 1u) == gridDim.x - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (tid == 0) {   // frame bases: a few thousand frames at most, one lane
-        const uint64_t meta = 32ull + 3ull * p.T;
-        uint64_t at = 0;
-        for (uint32_t g = 0; g < gridDim.x; g++) {
-            const uint32_t words = __hip_atomic_load(&p.frame_words[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t fbase = p.slot_stride ? (uint64_t)g * p.slot_stride : at;
-            p.frame_base[g] = fbase;
-            if (p.frame_offsets) p.frame_offsets[g] = fbase;
-            if (p.frame_bytes) p.frame_bytes[g] = meta + 8ull * words;
-            at += meta + 8ull * words;
-        }
-        *p.arrivals = 0;   // clean for the next launch
-    }
-}
-
-// ---- encode 3: pack ---------------------------------------------------------------------------------------------
 // Four pixels (two dwords, 16 bits each, already minus the minimum) -> the 4*d-bit integer p0 | p1<<d | p2<<2d | p3<<3d.
 __device__ __forceinline__ uint64_t pack4x16(uint32_t a, uint32_t b, uint32_t d) {
     const uint64_t lo = (uint64_t)(a & 0xFFFFu) | ((uint64_t)(a >> 16) << d);
@@ -158,24 +101,42 @@ __device__ __forceinline__ uint64_t pack4x16(uint32_t a, uint32_t b, uint32_t d)
     return lo | (hi << (2u * d));
 }
 
-__global__ __launch_bounds__(kChunkTiles16) void enc16_pack(Params16 p) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kChunkTiles16 * 16 + 64 * (kChunkTiles16 / 64)];   // 16 words per tile + trash words
+__device__ __forceinline__ bool spin_until(const u64a *word, u64a &value, uint64_t t_start) {
+    for (;;) {
+        value = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (value & kReady) return true;
+        if (wall_clock64() - t_start > 200000000ull) return false;   // 2 s at 100 MHz: give up, loudly
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+__global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kChunkTiles16 * 16 + kChunkTiles16];   // 16 words per tile + a trash word per lane
     __shared__ uint32_t s_tot[kChunkTiles16 / 64];
+    __shared__ uint32_t s_chunk, s_ok;
+    __shared__ unsigned long long s_pre[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const Tile16 k = tile_of(p, blockIdx.x, tid);
+    if (tid == 0) s_chunk = atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const uint32_t c = __builtin_amdgcn_readfirstlane(s_chunk);
+    const Tile16 k = tile_of(p, c, tid);
     uint32_t v[32];
     load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
-    const uint32_t d = k.has ? p.ws_depth[(size_t)k.f * p.T + k.t] : 0u;
-    const uint32_t mn = k.has ? p.ws_min[(size_t)k.f * p.T + k.t] : 0u;
+    uint32_t mn, mx;
+    tile_minmax16(v, mn, mx);
+    const uint32_t d = k.has ? depth_of(mx - mn) : 0u;
     const uint32_t incl = wave_scan_incl(d);
     if (lane == 63u) s_tot[wave] = incl;
     __syncthreads();
     uint32_t wbase = 0, total = 0;
     for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) { wbase += q < wave ? s_tot[q] : 0u; total += s_tot[q]; }
-    // straight-line funnel over 16 half rows of 4*d <= 64 bits (every half row stores the word it is filling)
+    if (tid == 0) __hip_atomic_store(&p.state[c], kReady | (u64a)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // pack while the record travels: straight-line funnel over 16 half rows of 4*d <= 64 bits (every half row
+    // stores the word it is filling; a tile without payload stores into the lane's trash word)
     const uint32_t mn2 = mn * 0x00010001u;   // every 16-bit half >= mn: no borrow crosses a half
     const uint32_t nb = 4u * d;
-    uint32_t q = d ? wbase + incl - d : kChunkTiles16 * 16u + tid;   // word index in the chunk image (trash word without payload)
+    uint32_t q = d ? wbase + incl - d : kChunkTiles16 * 16u + tid;
     uint64_t acc = 0;
     uint32_t fill = 0;
 #pragma unroll
@@ -189,26 +150,74 @@ __global__ __launch_bounds__(kChunkTiles16) void enc16_pack(Params16 p) {
         fill = nf & 63u;
         q += emit ? 1u : 0u;
     }
-    __syncthreads();
-    // metadata of this lane's tile, then the chunk's contiguous payload
+
+    // prefix inside the frame = sum of the records of the frame's chunks in front of this one; frame base
     const uint64_t meta = 32ull + 3ull * p.T;
-    uint8_t *fb = p.out + p.frame_base[k.f];
-    if (k.has) {
+    if (wave == 0) {
+        // decoupled look-back, 64 records per poll: lane l holds the record of chunk hi-1-l.  The nearest record that
+        // already carries an INCLUSIVE prefix (bit 62) ends the walk; everything nearer must at least be published.
+        const uint64_t t_start = wall_clock64();
+        const uint32_t fstart = k.f * p.chunks_per_frame;
+        uint32_t sum = 0, ok = 1u, hi = c;
+        while (hi > fstart && ok) {
+            const uint32_t span = hi - fstart < 64u ? hi - fstart : 64u;
+            const bool mine = lane < span;
+            u64a w = 0;
+            uint32_t L;
+            for (;;) {
+                w = mine ? __hip_atomic_load(&p.state[hi - 1u - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const uint64_t inc = __ballot(mine && (w & kInc) != 0ull), rdy = __ballot(!mine || (w & kReady) != 0ull);
+                L = inc ? (uint32_t)__builtin_ctzll(inc) : span;            // nearest inclusive record (or none in this window)
+                const uint64_t need = L >= 64u ? ~0ull : ((2ull << L) - 1ull);   // lanes 0..L must be there
+                if ((rdy & need) == need) break;
+                if (wall_clock64() - t_start > 200000000ull) { ok = 0u; break; }   // 2 s: give up, loudly
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const uint32_t v = mine && lane <= L ? (uint32_t)w : 0u;   // totals of the nearer chunks + the inclusive prefix at L
+            sum += (uint32_t)__builtin_amdgcn_readlane(wave_scan_incl(v), 63);
+            if (L < span) break;      // met an inclusive prefix
+            hi -= span;
+        }
+        // upgrade this chunk's record to inclusive: successors stop here
+        if (lane == 0 && ok) __hip_atomic_store(&p.state[c], kReady | kInc | (u64a)(sum + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64a fbase = p.slot_stride ? (kReady | (u64a)((uint64_t)k.f * p.slot_stride)) : kReady;
+        if (!p.slot_stride && k.f != 0u && ok) {   // concatenated: the previous frame's last chunk publishes this frame's base
+            if (lane == 0 && !spin_until(&p.frame_base[k.f], fbase, t_start)) ok = 0u;
+            fbase = __shfl(fbase, 0, 64);
+            ok = __all((int)ok) ? 1u : 0u;
+        }
+        if (lane == 0) {
+            s_pre[0] = sum; s_pre[1] = fbase & ~kReady; s_ok = ok;
+            if (!ok) atomicOr(p.sticky, 1u);
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const uint32_t inf = (uint32_t)s_pre[0];
+    uint8_t *fb = p.out + s_pre[1];
+    if (k.has) {   // metadata of this lane's tile
         fb[24 + k.t] = (uint8_t)d;
         uint8_t *m = fb + 28 + p.T + 2ull * k.t;
         m[0] = (uint8_t)mn; m[1] = (uint8_t)(mn >> 8);
     }
-    const uint32_t chunk_off = p.chunk_words[blockIdx.x];   // exclusive offset inside the frame (enc16_scan)
-    uint8_t *dst = fb + meta + 8ull * chunk_off;
+    uint8_t *dst = fb + meta + 8ull * inf;   // the chunk's contiguous payload
     for (uint32_t i = tid; i < total; i += kChunkTiles16) store_u64_any(dst + 8ull * i, s_pay[i]);
-    if (tid == 0 && k.cf == 0u) {   // frame header and the I32 fields (trap T1: elapsed travels as an F64; 0 here)
-        const uint64_t index = p.first_index + k.f;
-        store_u32_bytes(fb, 2u);
-        store_u64_any(fb + 4, index);
-        store_u64_any(fb + 12, 0ull);
-        store_u32_bytes(fb + 20, p.T);
-        store_u32_bytes(fb + 24 + p.T, 2u * p.T);
-        store_u32_bytes(fb + 28 + 3ull * p.T, p.frame_words[k.f]);
+    if (tid == 0) {
+        if (k.cf == 0u) {   // frame header and the first I32 fields (trap T1: elapsed travels as an F64; 0 here)
+            store_u32_bytes(fb, 2u);
+            store_u64_any(fb + 4, p.first_index + k.f);
+            store_u64_any(fb + 12, 0ull);
+            store_u32_bytes(fb + 20, p.T);
+            store_u32_bytes(fb + 24 + p.T, 2u * p.T);
+            if (p.frame_offsets) p.frame_offsets[k.f] = s_pre[1];
+        }
+        if (k.cf == p.chunks_per_frame - 1u) {   // the frame's word count is known here
+            const uint32_t words = inf + total;
+            store_u32_bytes(fb + 28 + 3ull * p.T, words);
+            if (p.frame_bytes) p.frame_bytes[k.f] = meta + 8ull * words;
+            if (!p.slot_stride && k.f + 1u < p.n_frames)
+                __hip_atomic_store(&p.frame_base[k.f + 1u], kReady | (u64a)(s_pre[1] + meta + 8ull * words), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -298,9 +307,7 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
 
 hipError_t launch_encode16(const Params16 &p, int n_frames, hipStream_t s) {
     const uint32_t n_chunks = (uint32_t)n_frames * p.chunks_per_frame;
-    hipLaunchKernelGGL(enc16_stats, dim3(n_chunks), dim3(kChunkTiles16), 0, s, p);
-    hipLaunchKernelGGL(enc16_scan, dim3(n_frames), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(enc16_pack, dim3(n_chunks), dim3(kChunkTiles16), 0, s, p);
+    hipLaunchKernelGGL(enc16_kernel, dim3(n_chunks), dim3(kChunkTiles16), 0, s, p);
     return hipGetLastError();
 }
 

@@ -556,14 +556,11 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     if ((uint64_t)n_frames * cpf >= (1ull << 31) || (uint64_t)g.T * 16ull >= (1ull << 32))
         return fail(ctx, DBDE_HIP_ERR_ARG, "encode16: launch too large");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // workspace: [arrivals 16 B][frame_base 8n][frame_words 4n][chunk_words 4 n cpf][ws_min 2 n T][ws_depth n T]
+    // workspace, zeroed before the launch: [ticket 16 B][frame_base 8n][state 8 n cpf]
     const size_t n = (size_t)n_frames;
-    const size_t o_base = 16, o_fw = o_base + 8 * n, o_cw = o_fw + 4 * n, o_min = (o_cw + 4 * n * cpf + 15) & ~(size_t)15,
-                 o_dep = o_min + 2 * n * g.T, need = o_dep + n * g.T + 64;
-    const size_t had = ctx->w16_bytes;
-    int rc = grow(ctx, ctx->w16, ctx->w16_bytes, need, 1);
+    const size_t need = 16 + 8 * n + 8 * n * cpf;
+    int rc = grow(ctx, ctx->w16, ctx->w16_bytes, need, 1, true);
     if (rc) return rc;
-    if (ctx->w16_bytes != had) HIP_TRY(ctx, hipMemsetAsync(ctx->w16, 0, 16, ctx->stream));   // the arrival counter keeps itself zero
     dbde16::Params16 p;
     p.images = d_images;
     p.out = d_out;
@@ -574,13 +571,13 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     p.frame_pixels = g.pixels;
     p.W = W; p.H = H; p.w = g.w; p.h = g.h; p.T = g.T;
     p.chunks_per_frame = cpf;
-    p.arrivals = reinterpret_cast<uint32_t *>(ctx->w16);
-    p.frame_base = reinterpret_cast<uint64_t *>(ctx->w16 + o_base);
-    p.frame_words = reinterpret_cast<uint32_t *>(ctx->w16 + o_fw);
-    p.chunk_words = reinterpret_cast<uint32_t *>(ctx->w16 + o_cw);
-    p.ws_min = reinterpret_cast<uint16_t *>(ctx->w16 + o_min);
-    p.ws_depth = ctx->w16 + o_dep;
+    p.n_frames = (uint32_t)n_frames;
+    p.ticket = reinterpret_cast<uint32_t *>(ctx->w16);
+    p.frame_base = reinterpret_cast<unsigned long long *>(ctx->w16 + 16);
+    p.state = p.frame_base + n;
+    p.sticky = ctx->sticky;
     span_begin(ctx, 0);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->w16, 0, need, ctx->stream));
     HIP_TRY(ctx, dbde16::launch_encode16(p, n_frames, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;

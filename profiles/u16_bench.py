@@ -35,6 +35,6 @@ dt = (time.perf_counter() - t0) / steps
 tk = codec.timing_read()
 raw = n * W * H * 2
 enc, idx, dec = tk["encode"][0] / steps, tk["decode_index"][0] / steps, tk["decode"][0] / steps
-print(f"DBDE16 {n} x {W}x{H}: packed/raw {packed/raw:.3f}; encode (3 kernels, pixels read twice) {enc:.3f} ms = "
+print(f"DBDE16 {n} x {W}x{H}: packed/raw {packed/raw:.3f}; encode (single pass, decoupled look-back) {enc:.3f} ms = "
       f"{(raw + packed)/enc/1e6:.0f} GB/s algorithmic ({(raw+packed)/enc/1e6/8000:.3f} of 8 TB/s); decode {dec:.3f} ms + index {idx:.3f} ms = "
       f"{(raw + packed)/dec/1e6:.0f} GB/s ({(raw+packed)/dec/1e6/8000:.3f}); round trip {n/dt:.0f} frames/s")

@@ -379,7 +379,9 @@ def main():
     # (DBDE_BENCH_REHEARSAL=nccl: the same with the RCCL backend, where the runtime accepts two ranks on one device)
     rehearsal = os.environ.get("DBDE_BENCH_REHEARSAL") in ("1", "nccl")
     rehearsal_nccl = os.environ.get("DBDE_BENCH_REHEARSAL") == "nccl"
-    if world > 1:
+    # DBDE_BENCH_FORCE_DIST=1: build the process group even for one rank (a one-GPU box can then run the RCCL
+    # init / barrier / all-reduce / size all-gather calls of the N > 1 path; RANK, WORLD_SIZE=1, MASTER_* from the env)
+    if world > 1 or os.environ.get("DBDE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dry_run:

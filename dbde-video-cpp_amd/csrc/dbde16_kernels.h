@@ -21,10 +21,13 @@ struct Params16 {                   // encode
     uint32_t w, h, T, chunks_per_frame;
     uint32_t n_frames;
     // workspace, zeroed before every launch
-    unsigned long long *state;      // [n_frames * cpf] bit 63 = published, low 32 bits = payload words of the chunk
-    unsigned long long *frame_base; // [n_frames] bit 63 = known, rest = byte offset of the frame from `out` (concatenated layout)
+    unsigned long long *state;      // [n_frames * cpf] bit 63 = published, rest = payload words of the chunk
+    unsigned long long *gsum;       // [n_frames * ceil(cpf / 64)] words of a frame's group of 64 chunks
+    unsigned long long *fsize;      // [n_frames] words of a frame (concatenated layout)
+    unsigned long long *fgsum;      // [ceil(n_frames / 64)] words of a group of 64 frames (concatenated layout)
     uint32_t *ticket;               // chunk ids are arrival tickets
     uint32_t *sticky;               // context-wide failure word, OR-ed on a look-back time-out
+    unsigned long long *diag;       // -DDBDE_DIAG builds: phase time sums ([0..7], 10 ns ticks), else unused
 };
 
 struct DecParams16 {

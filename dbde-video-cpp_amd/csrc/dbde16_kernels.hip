@@ -6,7 +6,7 @@
 // Correctness-first companion of dbde_kernels.hip, same decomposition, ONE tile per lane (a tile row is 8 pixels =
 // 16 bytes, so every image access is still one 16-byte access per row and lane):
 //   encode: enc16_kernel  -- one pass: a workgroup per 256-tile chunk reduces, publishes its word count, packs, and
-//                            finds its prefix by decoupled look-back over the records in front of it (ticket order)
+//                            finds its prefix by summing the records in front of it (ticket order, two-level sums)
 //   decode: the 8-bit path's index kernels (IdxParams::min_bytes = 2) + dec16_kernel.
 // A tile row is the 8*d-bit integer at byte r*d of the tile payload, exactly as in the 8-bit format: rows are
 // assembled / taken apart as two 4-pixel halves of 4*d <= 64 bits.
@@ -86,13 +86,12 @@ __device__ __forceinline__ Tile16 tile_of(const Params16 &p, uint32_t c, uint32_
 // ---- encode: ONE pass ------------------------------------------------------------------------------------------
 // Workgroup = one chunk of 256 tiles, chunk id = arrival ticket (every chunk in front of a workgroup belongs to a
 // workgroup that is already running: no assumption about dispatch order).  Load, reduce, publish the chunk's word
-// count as an 8-byte record, pack into LDS while the record travels, then look back over the records in front of it
-// IN ITS FRAME (wave 0, 64 per poll) until one carries an inclusive prefix, upgrade its own record to inclusive, store.
-// Concatenated layout: the workgroup that holds a frame's last chunk knows the frame's byte count and publishes the
-// next frame's base; a chunk waits for its frame's base as it waits for its predecessors.  Records and bases are
-// zeroed before the launch (dbde16_hip_encode_frames).
+// count as an 8-byte record, pack into LDS while the record travels, then sum the records in front of it (wave 0;
+// two levels, groups of 64, so no record depends on a chain of earlier prefixes), store.
+// Concatenated layout: the workgroup that holds a frame's last chunk publishes the frame's word count; a frame's base
+// is the sum of the counts in front of it.  All records are zeroed before the launch (dbde16_hip_encode_frames).
 typedef unsigned long long u64a;
-constexpr u64a kReady = 1ull << 63, kInc = 1ull << 62;
+constexpr u64a kReady = 1ull << 63;
 
 // Four pixels (two dwords, 16 bits each, already minus the minimum) -> the 4*d-bit integer p0 | p1<<d | p2<<2d | p3<<3d.
 __device__ __forceinline__ uint64_t pack4x16(uint32_t a, uint32_t b, uint32_t d) {
@@ -101,13 +100,31 @@ __device__ __forceinline__ uint64_t pack4x16(uint32_t a, uint32_t b, uint32_t d)
     return lo | (hi << (2u * d));
 }
 
-__device__ __forceinline__ bool spin_until(const u64a *word, u64a &value, uint64_t t_start) {
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+// Wave-wide: sums of four record ranges (at most 64 records each: lane l reads record l of every range in one
+// poll), waiting until every record is published.  False after 2 s (the caller raises the sticky failure word).
+__device__ __forceinline__ uint32_t sum_records(const u64a *r0, uint32_t n0, const u64a *r1, uint32_t n1, const u64a *r2, uint32_t n2,
+                                                const u64a *r3, uint32_t n3, uint32_t lane, uint64_t t_start,
+                                                uint64_t &s0, uint64_t &s1, uint64_t &s2, uint64_t &s3) {
+    u64a w0 = kReady, w1 = kReady, w2 = kReady, w3 = kReady;
     for (;;) {
-        value = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (value & kReady) return true;
-        if (wall_clock64() - t_start > 200000000ull) return false;   // 2 s at 100 MHz: give up, loudly
-        __builtin_amdgcn_s_sleep(2);
+        if (lane < n0 && w0 == kReady) w0 = __hip_atomic_load(&r0[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < n1 && w1 == kReady) w1 = __hip_atomic_load(&r1[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < n2 && w2 == kReady) w2 = __hip_atomic_load(&r2[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < n3 && w3 == kReady) w3 = __hip_atomic_load(&r3[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)(((w0 & w1 & w2 & w3) >> 63) & 1ull))) break;
+        if (wall_clock64() - t_start > 200000000ull) return 0u;   // 2 s at 100 MHz: give up, loudly
+        __builtin_amdgcn_s_sleep(1);
+        // records not there yet read as 0: mark them "to be read again"
+        w0 = (w0 & kReady) ? w0 : kReady; w1 = (w1 & kReady) ? w1 : kReady; w2 = (w2 & kReady) ? w2 : kReady; w3 = (w3 & kReady) ? w3 : kReady;
     }
+    s0 = wave_sum64(lane < n0 ? (w0 & ~kReady) : 0ull); s1 = wave_sum64(lane < n1 ? (w1 & ~kReady) : 0ull);
+    s2 = wave_sum64(lane < n2 ? (w2 & ~kReady) : 0ull); s3 = wave_sum64(lane < n3 ? (w3 & ~kReady) : 0ull);
+    return 1u;
 }
 
 __global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
@@ -116,9 +133,16 @@ __global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
     __shared__ uint32_t s_chunk, s_ok;
     __shared__ unsigned long long s_pre[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef DBDE_DIAG
+    uint64_t dt[6]; dt[0] = wall_clock64();
+#define DIAG_MARK(i) dt[i] = wall_clock64()
+#else
+#define DIAG_MARK(i)
+#endif
     if (tid == 0) s_chunk = atomicAdd(p.ticket, 1u);
     __syncthreads();
     const uint32_t c = __builtin_amdgcn_readfirstlane(s_chunk);
+    DIAG_MARK(1);
     const Tile16 k = tile_of(p, c, tid);
     uint32_t v[32];
     load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
@@ -131,6 +155,7 @@ __global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
     uint32_t wbase = 0, total = 0;
     for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) { wbase += q < wave ? s_tot[q] : 0u; total += s_tot[q]; }
     if (tid == 0) __hip_atomic_store(&p.state[c], kReady | (u64a)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DIAG_MARK(2);
 
     // pack while the record travels: straight-line funnel over 16 half rows of 4*d <= 64 bits (every half row
     // stores the word it is filling; a tile without payload stores into the lane's trash word)
@@ -151,48 +176,59 @@ __global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
         q += emit ? 1u : 0u;
     }
 
-    // prefix inside the frame = sum of the records of the frame's chunks in front of this one; frame base
+    // Prefix inside the frame and the frame's base WITHOUT a serial chain: two-level sums of records that each depend
+    // on published counts only.  A = the chunks in front of this one in its group of 64, B = the frame's groups in
+    // front (a group's count is published by its 64th chunk = A + own), C / D = the same two levels over frame word
+    // counts (concatenated layout; a frame's count is published by its last chunk).  One poll of four loads per lane.
     const uint64_t meta = 32ull + 3ull * p.T;
+    DIAG_MARK(3);
     if (wave == 0) {
-        // decoupled look-back, 64 records per poll: lane l holds the record of chunk hi-1-l.  The nearest record that
-        // already carries an INCLUSIVE prefix (bit 62) ends the walk; everything nearer must at least be published.
         const uint64_t t_start = wall_clock64();
-        const uint32_t fstart = k.f * p.chunks_per_frame;
-        uint32_t sum = 0, ok = 1u, hi = c;
-        while (hi > fstart && ok) {
-            const uint32_t span = hi - fstart < 64u ? hi - fstart : 64u;
-            const bool mine = lane < span;
-            u64a w = 0;
-            uint32_t L;
-            for (;;) {
-                w = mine ? __hip_atomic_load(&p.state[hi - 1u - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                const uint64_t inc = __ballot(mine && (w & kInc) != 0ull), rdy = __ballot(!mine || (w & kReady) != 0ull);
-                L = inc ? (uint32_t)__builtin_ctzll(inc) : span;            // nearest inclusive record (or none in this window)
-                const uint64_t need = L >= 64u ? ~0ull : ((2ull << L) - 1ull);   // lanes 0..L must be there
-                if ((rdy & need) == need) break;
-                if (wall_clock64() - t_start > 200000000ull) { ok = 0u; break; }   // 2 s: give up, loudly
-                __builtin_amdgcn_s_sleep(1);
-            }
-            const uint32_t v = mine && lane <= L ? (uint32_t)w : 0u;   // totals of the nearer chunks + the inclusive prefix at L
-            sum += (uint32_t)__builtin_amdgcn_readlane(wave_scan_incl(v), 63);
-            if (L < span) break;      // met an inclusive prefix
-            hi -= span;
+        const uint32_t g = k.cf >> 6, nA = k.cf & 63u, gpf = (p.chunks_per_frame + 63u) >> 6;
+        const bool concat = p.slot_stride == 0ull;
+        const uint32_t nC = concat ? (k.f & 63u) : 0u, fg = concat ? (k.f >> 6) : 0u;
+        const u64a *rA = p.state + (size_t)k.f * p.chunks_per_frame + (size_t)g * 64u;
+        const u64a *rB = p.gsum + (size_t)k.f * gpf;
+        const u64a *rC = p.fsize + (size_t)(k.f & ~63u);
+        uint64_t sA = 0, sB = 0, sC = 0, sD = 0, z0, z1, z2;
+        uint32_t ok = 1u;
+        const uint32_t nB = g < 64u ? g : 64u, nD = fg < 64u ? fg : 64u;
+        const bool pub_group = nA == 63u, pub_frame = concat && k.cf == p.chunks_per_frame - 1u;
+        if (!pub_group && !pub_frame) {
+            ok = sum_records(rA, nA, rB, nB, rC, nC, p.fgsum, nD, lane, t_start, sA, sB, sC, sD);
+        } else {   // a chunk that publishes a higher-level record does so BEFORE it waits for records of that level
+            ok = sum_records(rA, nA, rA, 0u, rA, 0u, rA, 0u, lane, t_start, sA, z0, z1, z2);
+            if (pub_group && lane == 0 && ok)
+                __hip_atomic_store(&p.gsum[(size_t)k.f * gpf + g], kReady | (u64a)(sA + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok) ok = sum_records(rB, nB, rC, nC, rA, 0u, rA, 0u, lane, t_start, sB, sC, z0, z1);
         }
-        // upgrade this chunk's record to inclusive: successors stop here
-        if (lane == 0 && ok) __hip_atomic_store(&p.state[c], kReady | kInc | (u64a)(sum + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u64a fbase = p.slot_stride ? (kReady | (u64a)((uint64_t)k.f * p.slot_stride)) : kReady;
-        if (!p.slot_stride && k.f != 0u && ok) {   // concatenated: the previous frame's last chunk publishes this frame's base
-            if (lane == 0 && !spin_until(&p.frame_base[k.f], fbase, t_start)) ok = 0u;
-            fbase = __shfl(fbase, 0, 64);
-            ok = __all((int)ok) ? 1u : 0u;
+        for (uint32_t i = 64u; i < g && ok; i += 64u) {    // frames of more than 4096 chunks
+            uint64_t x = 0;
+            ok = sum_records(rB + i, g - i < 64u ? g - i : 64u, rA, 0u, rA, 0u, rA, 0u, lane, t_start, x, z0, z1, z2);
+            sB += x;
+        }
+        const uint64_t inf = sA + sB, fwords = inf + total;
+        if (pub_frame && lane == 0 && ok) {
+            __hip_atomic_store(&p.fsize[k.f], kReady | (u64a)fwords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nC == 63u) __hip_atomic_store(&p.fgsum[fg], kReady | (u64a)(sC + fwords), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if ((pub_group || pub_frame) && ok) ok = sum_records(p.fgsum, nD, rA, 0u, rA, 0u, rA, 0u, lane, t_start, sD, z0, z1, z2);
+        for (uint32_t i = 64u; i < fg && ok; i += 64u) {   // launches of more than 4096 frames
+            uint64_t x = 0;
+            ok = sum_records(p.fgsum + i, fg - i < 64u ? fg - i : 64u, rA, 0u, rA, 0u, rA, 0u, lane, t_start, x, z0, z1, z2);
+            sD += x;
         }
         if (lane == 0) {
-            s_pre[0] = sum; s_pre[1] = fbase & ~kReady; s_ok = ok;
+            s_pre[0] = inf;
+            s_pre[1] = concat ? (uint64_t)k.f * meta + 8ull * (sC + sD) : (uint64_t)k.f * p.slot_stride;
+            s_ok = ok;
             if (!ok) atomicOr(p.sticky, 1u);
         }
     }
+    DIAG_MARK(4);
     __syncthreads();
     if (!s_ok) return;
+    DIAG_MARK(5);
     const uint32_t inf = (uint32_t)s_pre[0];
     uint8_t *fb = p.out + s_pre[1];
     if (k.has) {   // metadata of this lane's tile
@@ -201,7 +237,20 @@ __global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
         m[0] = (uint8_t)mn; m[1] = (uint8_t)(mn >> 8);
     }
     uint8_t *dst = fb + meta + 8ull * inf;   // the chunk's contiguous payload
-    for (uint32_t i = tid; i < total; i += kChunkTiles16) store_u64_any(dst + 8ull * i, s_pay[i]);
+    if ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0u) {   // word-aligned: 16-byte stores between a possible odd first and last word
+        const uint32_t head = (uint32_t)(reinterpret_cast<uintptr_t>(dst) >> 3) & 1u;
+        const uint32_t h1 = head < total ? head : total;
+        if (tid == 0 && h1) *reinterpret_cast<uint64_t *>(dst) = s_pay[0];
+        const uint32_t pairs = (total - h1) >> 1;
+        typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
+        for (uint32_t i = tid; i < pairs; i += kChunkTiles16) {
+            u64x2_t q = {s_pay[h1 + 2u * i], s_pay[h1 + 2u * i + 1u]};
+            *reinterpret_cast<u64x2_t *>(dst + 8ull * (h1 + 2u * i)) = q;
+        }
+        if (tid == 64u && ((total - h1) & 1u)) *reinterpret_cast<uint64_t *>(dst + 8ull * (total - 1u)) = s_pay[total - 1u];
+    } else {
+        for (uint32_t i = tid; i < total; i += kChunkTiles16) store_u64_any(dst + 8ull * i, s_pay[i]);
+    }
     if (tid == 0) {
         if (k.cf == 0u) {   // frame header and the first I32 fields (trap T1: elapsed travels as an F64; 0 here)
             store_u32_bytes(fb, 2u);
@@ -215,10 +264,17 @@ __global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
             const uint32_t words = inf + total;
             store_u32_bytes(fb + 28 + 3ull * p.T, words);
             if (p.frame_bytes) p.frame_bytes[k.f] = meta + 8ull * words;
-            if (!p.slot_stride && k.f + 1u < p.n_frames)
-                __hip_atomic_store(&p.frame_base[k.f + 1u], kReady | (u64a)(s_pre[1] + meta + 8ull * words), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef DBDE_DIAG
+    if (tid == 0 && (c & 63u) == 5u) {   // a sample of workgroups, wave 0's view: ticket | load+reduce | pack | look-back | barrier wait | store
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t t6 = wall_clock64();
+        for (int i = 0; i < 5; i++) atomicAdd(&p.diag[i], (unsigned long long)(dt[i + 1] - dt[i]));
+        atomicAdd(&p.diag[5], (unsigned long long)(t6 - dt[5]));
+        atomicAdd(&p.diag[6], 1ull);
+    }
+#endif
 }
 
 // ---- decode ---------------------------------------------------------------------------------------------------

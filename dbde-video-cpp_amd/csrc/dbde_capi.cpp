@@ -556,9 +556,9 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     if ((uint64_t)n_frames * cpf >= (1ull << 31) || (uint64_t)g.T * 16ull >= (1ull << 32))
         return fail(ctx, DBDE_HIP_ERR_ARG, "encode16: launch too large");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // workspace, zeroed before the launch: [ticket 16 B][frame_base 8n][state 8 n cpf]
-    const size_t n = (size_t)n_frames;
-    const size_t need = 16 + 8 * n + 8 * n * cpf;
+    // workspace, zeroed before the launch: [ticket 16 B][state 8 n cpf][gsum 8 n gpf][fsize 8 n][fgsum 8 ceil(n / 64)]
+    const size_t n = (size_t)n_frames, gpf = (cpf + 63) / 64;
+    const size_t need = 16 + 8 * (n * cpf + n * gpf + n + (n + 63) / 64);
     int rc = grow(ctx, ctx->w16, ctx->w16_bytes, need, 1, true);
     if (rc) return rc;
     dbde16::Params16 p;
@@ -573,9 +573,12 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     p.chunks_per_frame = cpf;
     p.n_frames = (uint32_t)n_frames;
     p.ticket = reinterpret_cast<uint32_t *>(ctx->w16);
-    p.frame_base = reinterpret_cast<unsigned long long *>(ctx->w16 + 16);
-    p.state = p.frame_base + n;
+    p.state = reinterpret_cast<unsigned long long *>(ctx->w16 + 16);
+    p.gsum = p.state + n * cpf;
+    p.fsize = p.gsum + n * gpf;
+    p.fgsum = p.fsize + n;
     p.sticky = ctx->sticky;
+    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     span_begin(ctx, 0);
     HIP_TRY(ctx, hipMemsetAsync(ctx->w16, 0, need, ctx->stream));
     HIP_TRY(ctx, dbde16::launch_encode16(p, n_frames, ctx->stream));

@@ -38,3 +38,12 @@ enc, idx, dec = tk["encode"][0] / steps, tk["decode_index"][0] / steps, tk["deco
 print(f"DBDE16 {n} x {W}x{H}: packed/raw {packed/raw:.3f}; encode (single pass, decoupled look-back) {enc:.3f} ms = "
       f"{(raw + packed)/enc/1e6:.0f} GB/s algorithmic ({(raw+packed)/enc/1e6/8000:.3f} of 8 TB/s); decode {dec:.3f} ms + index {idx:.3f} ms = "
       f"{(raw + packed)/dec/1e6:.0f} GB/s ({(raw+packed)/dec/1e6/8000:.3f}); round trip {n/dt:.0f} frames/s")
+if os.environ.get("U16_DIAG"):   # -DDBDE_DIAG builds: wave 0's phase times of the encoder, per workgroup
+    import ctypes as C
+    d = (C.c_uint64 * 16)()
+    codec.L.dbde_hip_diag_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    codec.L.dbde_hip_diag_read(codec.h, d)
+    codec.sync()
+    wg = max(d[6], 1)
+    names = ["ticket", "load+reduce+publish", "pack", "look-back", "barrier", "store"]
+    print("enc16 per workgroup (us): " + ", ".join(f"{nm} {d[i] / wg / 100:.2f}" for i, nm in enumerate(names)) + f"  [{wg} workgroups]")

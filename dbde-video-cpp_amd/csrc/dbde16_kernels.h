@@ -40,6 +40,7 @@ struct DecParams16 {
     uint64_t frame_pixels;
     int W, H;
     uint32_t w, h, T, chunks_per_frame;
+    unsigned long long *diag;       // -DDBDE_DIAG builds only
 };
 
 hipError_t launch_encode16(const Params16 &p, int n_frames, hipStream_t s);

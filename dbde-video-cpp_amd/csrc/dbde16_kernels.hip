@@ -282,11 +282,18 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kChunkTiles16 * 128 + 48];
     __shared__ uint32_t s_tot[kChunkTiles16 / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef DBDE_DIAG
+    uint64_t dt[5]; dt[0] = wall_clock64();
+#endif
     const uint32_t c = blockIdx.x, f = c / p.chunks_per_frame, cf = c - f * p.chunks_per_frame;
-    if (!p.frame_ok[f]) return;   // rejected frame: image untouched
-    const uint8_t *fb = p.stream + p.frame_offsets[f];
+    // the three index words are requested together (one memory round trip, not three), then looked at
     const uint32_t *co = p.chunk_off + (size_t)f * (p.chunks_per_frame + 1u) + cf;
-    const uint32_t w_begin = co[0], words = co[1] - co[0];
+    const uint32_t ok = p.frame_ok[f], w_begin = co[0], w_end = co[1];
+    const uint64_t f_off = p.frame_offsets[f];
+    asm volatile("" :: "s"(w_begin), "s"(w_end), "s"(f_off));   // ... before the branch
+    if (!ok) return;   // rejected frame: image untouched
+    const uint8_t *fb = p.stream + f_off;
+    const uint32_t words = w_end - w_begin;
     const uint32_t t = cf * kChunkTiles16 + tid;
     const bool has = t < p.T;
     // the chunk's payload: one contiguous byte range, fetched as aligned 16-byte pieces (source aligned down; the
@@ -295,28 +302,44 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
     const uint8_t *asrc = src - shift;
     const uint32_t n16 = (shift + 8u * words + 15u) >> 4;
-    for (uint32_t i = tid; i < n16; i += kChunkTiles16) {
-        u32x4_t q;
-        if (asrc + 16ull * (i + 1u) <= p.stream + p.stream_bytes) q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(asrc + 16ull * i));
-        else {   // the piece would cross the end of the readable extent: byte by byte
-            uint32_t wq[4] = {0, 0, 0, 0};
-            for (uint32_t b = 0; b < 16u; b++) {
-                const uint8_t *s1 = asrc + 16ull * i + b;
-                if (s1 < p.stream + p.stream_bytes) wq[b >> 2] |= (uint32_t)*s1 << (8u * (b & 3u));
-            }
-            q[0] = wq[0]; q[1] = wq[1]; q[2] = wq[2]; q[3] = wq[3];
-        }
-        *reinterpret_cast<u32x4_t *>(s_in + 16u * i) = q;
-    }
-    uint32_t d = 0, mn = 0;
+    uint32_t d = 0, mn = 0;   // this lane's tile: depth and minimum, in flight with the payload
     if (has) {
         d = fb[24 + t];
         const uint8_t *m = fb + 28 + p.T + 2ull * t;
         mn = (uint32_t)m[0] | ((uint32_t)m[1] << 8);
     }
+    // whole pieces inside the readable extent: all of a thread's loads (at most 8: 256 tiles x 128 bytes + the
+    // shift) are in flight before the first is stored, one memory round trip for the chunk
+    const uint64_t room = (uint64_t)((p.stream + p.stream_bytes) - asrc);
+    const uint32_t n16_in = room / 16u < (uint64_t)n16 ? (uint32_t)(room / 16u) : n16;
+    {
+        constexpr int kMaxPieces = (kChunkTiles16 * 128 + 16 + 16 * kChunkTiles16 - 1) / (16 * kChunkTiles16);   // 9: the shift may add one
+        u32x4_t q[kMaxPieces];
+#pragma unroll
+        for (int j = 0; j < kMaxPieces; j++) {
+            const uint32_t i = tid + (uint32_t)j * kChunkTiles16;
+            if (i < n16_in) q[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(asrc + 16ull * i));
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxPieces; j++) {
+            const uint32_t i = tid + (uint32_t)j * kChunkTiles16;
+            if (i < n16_in) *reinterpret_cast<u32x4_t *>(s_in + 16u * i) = q[j];
+        }
+    }
+    for (uint32_t i = n16_in + tid; i < n16; i += kChunkTiles16) {   // a piece that would cross the end of the extent: byte by byte
+        uint32_t wq[4] = {0, 0, 0, 0};
+        for (uint32_t b = 0; b < 16u; b++) {
+            const uint8_t *s1 = asrc + 16ull * i + b;
+            if (s1 < p.stream + p.stream_bytes) wq[b >> 2] |= (uint32_t)*s1 << (8u * (b & 3u));
+        }
+        u32x4_t q = {wq[0], wq[1], wq[2], wq[3]};
+        *reinterpret_cast<u32x4_t *>(s_in + 16u * i) = q;
+    }
     const uint32_t incl = wave_scan_incl(d);
     if (lane == 63u) s_tot[wave] = incl;
+    DIAG_MARK(1);
     __syncthreads();
+    DIAG_MARK(2);
     uint32_t wbase = 0;
     for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) wbase += q < wave ? s_tot[q] : 0u;
     if (!has) return;
@@ -338,6 +361,7 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    DIAG_MARK(3);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint64_t h2 = hi[r] >> ((d & 1u) * 4u);
@@ -359,6 +383,13 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
             }
         }
     }
+#ifdef DBDE_DIAG
+    if (tid == 0 && (c & 63u) == 5u) {   // a sample of workgroups: fetch issue | barrier | LDS reads | unpack + stores (issue)
+        DIAG_MARK(4);
+        for (int i = 0; i < 4; i++) atomicAdd(&p.diag[8 + i], (unsigned long long)(dt[i + 1] - dt[i]));
+        atomicAdd(&p.diag[12], 1ull);
+    }
+#endif
 }
 
 hipError_t launch_encode16(const Params16 &p, int n_frames, hipStream_t s) {

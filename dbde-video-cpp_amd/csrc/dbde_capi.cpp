@@ -629,6 +629,7 @@ int dbde16_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t 
     p.frame_pixels = g.pixels;
     p.W = W; p.H = H; p.w = g.w; p.h = g.h; p.T = g.T;
     p.chunks_per_frame = dg.cpf;
+    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     span_begin(ctx, 2);
     HIP_TRY(ctx, dbde16::launch_decode16(p, n_frames, ctx->stream));
     span_end(ctx);

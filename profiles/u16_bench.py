@@ -46,4 +46,6 @@ if os.environ.get("U16_DIAG"):   # -DDBDE_DIAG builds: wave 0's phase times of t
     codec.sync()
     wg = max(d[6], 1)
     names = ["ticket", "load+reduce+publish", "pack", "look-back", "barrier", "store"]
+    wd = max(d[12], 1)
+    print("dec16 per workgroup (us): " + ", ".join(f"{nm} {d[8 + i] / wd / 100:.2f}" for i, nm in enumerate(["fetch issue", "barrier", "LDS reads", "unpack+store issue"])) + f"  [{wd} workgroups]")
     print("enc16 per workgroup (us): " + ", ".join(f"{nm} {d[i] / wg / 100:.2f}" for i, nm in enumerate(names)) + f"  [{wg} workgroups]")

@@ -1470,6 +1470,11 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         const uint32_t ok = p.frame_ok[f];
         const uint32_t *co = p.chunk_off + (size_t)f * (p.chunks_per_frame + 1u) + cf;
         w_begin = co[0]; w_end = co[1];
+#ifndef DBDE_IDX_SERIAL
+        // ... and really together: without this the compiler sinks the loads behind the branch (three dependent
+        // scalar round trips before the first payload byte is requested)
+        asm volatile("" :: "s"(ok), "s"(w_begin), "s"(w_end), "s"((uint32_t)foff));
+#endif
         if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
     }
 

@@ -91,7 +91,20 @@ __global__ __launch_bounds__(256) void generic(uint8_t *img, int W, int H, uint3
         size_t x0 = 8u * tx;
         if (x0 + 16 > (size_t)W) x0 = (size_t)W - 16;      // stay inside the row (edge fix-up is ALU work)
         uint8_t *p = base + (size_t)yy * (size_t)W + x0;
-        if (MODE == 0) {
+        if (MODE == 3) {   // WRITE only: lane j stores the ALIGNED block that follows its address (own tail + next lane's head);
+                           // lanes that start / end a run (wave edge, image-row edge) store their partial block bytewise
+            const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+            const uint32_t s = (uint32_t)(a & 15u);
+            const uint32_t lane = threadIdx.x & 63u;
+            const bool row_start = tx == 0u, row_end = tx + 2u >= w;
+            u32x4 v = {t0, t0, t0, t0};
+            if (s == 0u) { *reinterpret_cast<u32x4 *>(p) = v; }
+            else {
+                if (!(lane == 63u || row_end)) *reinterpret_cast<u32x4 *>(p + (16u - s)) = v;       // aligned: a - s + 16
+                else for (uint32_t b = 16u - s; b < 16u; b++) p[b] = (uint8_t)t0;                    // tail bytes of the run
+                if (lane == 0u || row_start) for (uint32_t b = 0; b < 16u - s; b++) p[b] = (uint8_t)t0;   // head bytes of the run
+            }
+        } else if (MODE == 0) {
             if (WRITE) { uint64_t v = t0; __builtin_memcpy(p, &v, 8); __builtin_memcpy(p + 8, &v, 8); }
             else { uint64_t a, b; __builtin_memcpy(&a, p, 8); __builtin_memcpy(&b, p + 8, 8); acc ^= (uint32_t)(a ^ b) ^ (uint32_t)((a ^ b) >> 32); }
         } else {
@@ -149,6 +162,8 @@ int main(int argc, char **argv) {
         timeit(name, [&] { hipLaunchKernelGGL((generic<0, true>), dim3(gb), dim3(256), 0, 0, a, W, H, w, T, cpf, sink); }, moved);
         snprintf(name, sizeof name, "W=%d write 1x16B", W);
         timeit(name, [&] { hipLaunchKernelGGL((generic<1, true>), dim3(gb), dim3(256), 0, 0, a, W, H, w, T, cpf, sink); }, moved);
+        snprintf(name, sizeof name, "W=%d write aligned blocks + edges", W);
+        timeit(name, [&] { hipLaunchKernelGGL((generic<3, true>), dim3(gb), dim3(256), 0, 0, a, W, H, w, T, cpf, sink); }, moved);
     }
     return 0;
 }

@@ -337,13 +337,14 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
         return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
     // How the pixels reach the image (decode_kernel<IMG>): direct register -> image stores are only FAST when a
-    // wave's 1 KB covers whole cache lines (W, the frame size and the base multiples of 128); widths that keep
-    // tile rows 8-byte aligned are staged in LDS and leave as whole cache lines of the chunk's byte range; odd
-    // widths store tile by tile.
+    // wave's 1 KB covers whole cache lines (W, the frame size and the base multiples of 128).  Other widths get
+    // chunks of whole tile rows where those fill a 512-tile workgroup to 90 % or more: the workgroup stages its pixels
+    // in LDS and writes whole cache lines of the chunk's byte range (odd widths: only workgroups whose tiles are all
+    // of depth 0 or 8, see the vote in decode_kernel).  Everything else stores tile by tile from plain chunks.
     const uintptr_t ib = reinterpret_cast<uintptr_t>(d_images);
     int img_mode = 2;
     if (W % 128 == 0 && g.pixels % 128 == 0 && (ib & 127u) == 0) img_mode = 0;
-    else if (W % 8 == 0 && (ib & 7u) == 0 && g.w <= kChunkTiles) img_mode = 1;
+    else if (g.w <= kChunkTiles && W >= 16 && (kChunkTiles / g.w) * g.w * 10u >= kChunkTiles * 9u) img_mode = 1;
 #ifdef DBDE_FORCE_GENERIC
     img_mode = 2;
 #endif

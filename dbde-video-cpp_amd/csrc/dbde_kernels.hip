@@ -1323,6 +1323,27 @@ __device__ __forceinline__ void lds_store_bytes(uint8_t *s_px, uint32_t a, uint6
     if (n & 1u) s_px[a] = (uint8_t)v;
 }
 
+// Staging at addresses that are not 8-byte aligned (odd widths): 8-byte LDS stores at odd addresses took five times
+// the aligned time inside the decode kernel, so a tile row is shifted in registers onto 4-byte aligned words.  `sr`
+// = address & 3 is the same for every tile of an image row; a tile owns the aligned words d0 = its first 4 - sr bytes
+// behind the last sr bytes of its LEFT neighbour (`prev`: that tile's upper dword) and d1; its own last sr bytes
+// travel in the right neighbour's d0.  The first tile of an image row has no left neighbour (its d0 spoils the last
+// bytes of the image row before) and the last one is not staged this way at all (it may be partial, and nobody
+// carries its last bytes): a second pass rewrites the last bytes of every image row (stage_row_end).
+__device__ __forceinline__ void stage_row_a4(uint8_t *s_px, uint32_t a4, uint32_t sr, uint32_t lo, uint32_t hi, uint32_t prev) {
+    const uint32_t sh = 4u - sr;   // 1..3 bytes are shifted (v_alignbyte_b32 takes the count modulo 4: sr == 0 is spelled out)
+    uint32_t *q = reinterpret_cast<uint32_t *>(s_px + a4);   // 4-byte aligned: ds_write2_b32
+    q[0] = sr ? __builtin_amdgcn_alignbyte(lo, prev, sh) : lo;
+    q[1] = sr ? __builtin_amdgcn_alignbyte(hi, lo, sh) : hi;
+}
+// The last tile of an image row (n = 1..8 valid bytes at byte address a): the three bytes in front of it (its left
+// neighbour's, when it has one) and its own, byte by byte.
+__device__ __forceinline__ void stage_row_end(uint8_t *s_px, uint32_t a, uint32_t lo, uint32_t hi, uint32_t prev, bool has_prev, uint32_t n) {
+    if (has_prev) { s_px[a - 3u] = (uint8_t)(prev >> 8); s_px[a - 2u] = (uint8_t)(prev >> 16); s_px[a - 1u] = (uint8_t)(prev >> 24); }
+    if (n == 8u) { __builtin_memcpy(s_px + a, &lo, 4); __builtin_memcpy(s_px + a + 4u, &hi, 4); }
+    else lds_store_bytes(s_px, a, ((uint64_t)hi << 32) | lo, n);
+}
+
 // Write one (possibly partial) tile: only the valid region (dbde_util.cpp:281-289).
 __device__ __forceinline__ void store_tile_generic(uint8_t *img, int W, int H, uint32_t w, uint32_t t,
                                                    const uint32_t (&v)[16]) {
@@ -1539,7 +1560,8 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     const uint32_t bA = shift + 8u * offA, bB = shift + 8u * offB;
     // wave-uniform specialisations: all tiles flat (depth 0), or all of depth 8 (rows are whole qwords)
     const bool all8 = (shift & 7u) == 0u && __all((int)(dA == 8u && dB == 8u));
-    if (__all((int)((dA | dB) == 0u))) {   // flat tiles only: every pixel is its tile's minimum, no payload
+    const bool flat = __all((int)((dA | dB) == 0u));
+    if (flat) {   // flat tiles only: every pixel is its tile's minimum, no payload
 #pragma unroll
         for (int i = 0; i < 16; i++) { va[i] = mA * 0x01010101u; vb[i] = mB * 0x01010101u; }
     } else if (all8) {
@@ -1594,8 +1616,75 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     // or the stores run at little more than half rate however well each lane is aligned (profiles/mempattern.hip)
     const uint32_t g7 = (uint32_t)(reinterpret_cast<uintptr_t>(g_first) & 127u);
     uint8_t *s_px = reinterpret_cast<uint8_t *>(s_in);
+    // Off 8-byte alignment (odd widths) the staging needs a re-alignment in registers: extra issue work that pays
+    // where the unpack was cheap -- workgroups whose tiles are all of depth 0 or 8: incompressible content, +16-19 %
+    // at 1921x1081 -- and costs 5 % where tiles are unpacked bit by bit, so such a workgroup stores tile by tile
+    // instead.  The vote rides on the barrier that hands the LDS over.  (8-byte aligned rows are always staged: on
+    // bit-packed content that equals tile-by-tile stores from plain chunks and beats them from these row chunks.)
+    const bool a8 = ((g7 | Wu) & 7u) == 0u;
+    __shared__ uint32_t s_edge[G::kWaves][8];
+    __shared__ uint32_t s_cheap[G::kWaves];
+    if (!a8 && lane == 63) {   // a wave's first lane needs the upper dwords of the tile left of it, which live in the wave before
+#pragma unroll
+        for (int r = 0; r < 8; r++) s_edge[wave][r] = vb[2 * r + 1];
+    }
+    if (!a8) {   // (lanes without a tile count as depth 0: a chunk's last, partly filled wave must not decide)
+        const bool simple = __all((int)((dA == 0u || dA == 8u) && (dB == 0u || dB == 8u)));
+        if (lane == 0) s_cheap[wave] = simple ? 1u : 0u;
+    }
     __syncthreads();   // every wave has finished reading the payload image: the memory changes hands
-    {
+    if (!a8) {
+        uint32_t cheap = 1u;
+#pragma unroll
+        for (int q = 0; q < G::kWaves; q++) cheap &= s_cheap[q];
+        if (!__builtin_amdgcn_readfirstlane(cheap)) {
+            if (hasA) store_tile_generic(img, p.W, p.H, p.w, t0, va);
+            if (hasB) store_tile_generic(img, p.W, p.H, p.w, t0 + 1u, vb);
+            return;
+        }
+    }
+    if (!a8) {
+        __shared__ uint64_t s_trash[64];
+        const uint32_t iA = 2u * (uint32_t)tid;
+        const uint32_t rowA = iA / wspan, colA = iA - rowA * wspan;
+        const uint32_t rowB = colA + 1u == wspan ? rowA + 1u : rowA, colB = colA + 1u == wspan ? 0u : colA + 1u;
+        const uint32_t nA = 8u * colA + 8u <= x_valid ? 8u : x_valid - 8u * colA;
+        const uint32_t nB = 8u * colB + 8u <= x_valid ? 8u : x_valid - 8u * colB;
+        const uint32_t aA = whole_rows ? g7 + 8u * rowA * Wu + 8u * colA : 8u * colA;
+        const uint32_t aB = whole_rows ? g7 + 8u * rowB * Wu + 8u * colB : 8u * colB;
+        const bool endA = hasA && colA + 1u == wspan, endB = hasB && colB + 1u == wspan;
+        const bool stageA = hasA && !endA, stageB = hasB && !endB;
+        const uint32_t trash = (uint32_t)(reinterpret_cast<uint8_t *>(&s_trash[lane]) - s_px);
+        uint32_t prevA[8];
+        // pass 1, no branches: every tile but the last of an image row (rows below the image's last, in the bottom
+        // chunk, are staged too: they lie behind the range that leaves)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t rt = whole_rows ? (uint32_t)r * Wu : ((g7 + (uint32_t)r * Wu) & 127u) + (uint32_t)r * l_pitch;
+            const uint32_t sr = (g7 + (uint32_t)r * Wu) & 3u;    // wave-uniform: tiles are 8 bytes apart, tile rows 8 * W
+            const uint32_t edge = wave > 0 ? s_edge[wave - 1][r] : 0u;
+            // left neighbour of tile A = tile B of the lane before (wave_shr:1; lane 0 keeps `edge`)
+            prevA[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)vb[2 * r + 1], 0x138, 0xF, 0xF, false);
+            stage_row_a4(s_px, stageA ? aA + rt - sr : trash, sr, va[2 * r], va[2 * r + 1], prevA[r]);
+            stage_row_a4(s_px, stageB ? aB + rt - sr : trash, sr, vb[2 * r], vb[2 * r + 1], va[2 * r + 1]);
+        }
+        __syncthreads();
+        // pass 2: the last bytes of every image row (after pass 1: the first tile of the next image row spoiled some)
+        if (endA) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t rt = whole_rows ? (uint32_t)r * Wu : ((g7 + (uint32_t)r * Wu) & 127u) + (uint32_t)r * l_pitch;
+                stage_row_end(s_px, aA + rt, va[2 * r], va[2 * r + 1], prevA[r], colA != 0u, nA);
+            }
+        }
+        if (endB) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t rt = whole_rows ? (uint32_t)r * Wu : ((g7 + (uint32_t)r * Wu) & 127u) + (uint32_t)r * l_pitch;
+                stage_row_end(s_px, aB + rt, vb[2 * r], vb[2 * r + 1], va[2 * r + 1], colB != 0u, nB);
+            }
+        }
+    } else {
         const uint32_t iA = 2u * (uint32_t)tid;
         const uint32_t rowA = iA / wspan, colA = iA - rowA * wspan;
         const uint32_t rowB = colA + 1u == wspan ? rowA + 1u : rowA, colB = colA + 1u == wspan ? 0u : colA + 1u;

@@ -337,6 +337,40 @@ def test_decode_reads_nothing_past_stream_bytes(codec, W, H, n, mode):
         assert rr[-1][0] == 0xFFFFFFFF and (back[-1] == 0xEE).all() and torch.equal(back[:-1], imgs[:-1])
 
 
+@pytest.mark.parametrize("W,H", [(17, 9), (23, 41), (31, 8), (33, 24), (63, 17), (65, 65), (100, 30), (121, 16),
+                                 (250, 33), (257, 8), (1001, 25), (1921, 17), (1922, 9), (1923, 16), (4093, 9)])
+def test_decode_staged_rows_off_alignment(codec, oracle, W, H):
+    """Widths whose image rows are not 8-byte aligned, content whose tiles are all of depth 0 or 8 (the workgroups
+    that stage their pixels in LDS, re-aligned in registers, and write whole cache lines) and bit-packed content
+    (the workgroups that store tile by tile), at every image base alignment mod 4 and a few mod 128; the bytes
+    around the images must stay untouched."""
+    import torch
+    n = 3
+    rng = np.random.default_rng(W * 131 + H)
+    noise = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    # tiles of depth 8 next to flat ones: rows of tiles alternate
+    flat8 = noise.copy()
+    for ty in range(0, (H + 7) // 8, 2):
+        flat8[:, 8 * ty: 8 * ty + 8, :] = 77
+    mixed = codec.synth_frames("mixed", SEED, 7, n, W, H).cpu().numpy()
+    for name, imgs_h in (("noise", noise), ("flat8", flat8), ("mixed", mixed)):
+        packed = [oracle.pack_frame(5 + f, imgs_h[f], W, H) for f in range(n)]
+        blob = np.concatenate(packed)
+        offs = torch.tensor(np.cumsum([0] + [len(x) for x in packed[:-1]]), dtype=torch.int64, device="cuda")
+        stream = torch.zeros(32 + len(blob) + 64, dtype=torch.uint8, device="cuda")
+        stream[32: 32 + len(blob)] = torch.from_numpy(blob).cuda()
+        for base in (0, 1, 2, 3, 5, 64, 127):
+            canvas = torch.full((256 + base + n * W * H + 256,), 0xEE, dtype=torch.uint8, device="cuda")
+            view = canvas[256 + base: 256 + base + n * W * H].view(n, H, W)
+            back, res = codec.decode_frames(stream, 32, len(blob), offs, W, H, n, images=view)
+            codec.sync()
+            got = canvas.cpu().numpy()
+            assert (got[:256 + base] == 0xEE).all() and (got[256 + base + n * W * H:] == 0xEE).all(), (W, H, name, base)
+            assert np.array_equal(got[256 + base: 256 + base + n * W * H].reshape(n, H, W), imgs_h), (W, H, name, base)
+            for f, r in enumerate(codec.parse_results(res)):
+                assert r == (2, 5 + f, 0, len(packed[f]))
+
+
 @pytest.mark.parametrize("name", ["cfg2_4096x3072", "cfg3_2048x2048", "cfg4_1921x1081"])
 def test_baseline_configs_full_size(codec, golden, name):
     """BASELINE.json configs 2-4: packed-frame hashes equal the REAL reference's (fixtures)."""

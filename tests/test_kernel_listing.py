@@ -93,7 +93,8 @@ def test_fast_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing, mangl
 
 def test_no_scratch_and_expected_occupancy(listing):
     """The hot kernels must not spill and must keep the residency the design assumes: encoder <= 128 VGPRs
-    (2 workgroups of 8 waves per CU), decoder <= 64 VGPRs (8 waves per SIMD allowed by registers)."""
+    (2 workgroups of 8 waves per CU); decoder: LDS (<= 40 KB) allows 4 workgroups = 4 waves per SIMD, registers must
+    not be what limits it (<= 96 leaves a fifth wave; the direct-image instances stay <= 64)."""
     meta = {}
     md = listing[listing.index("amdhsa.kernels:"):]
     for entry in re.split(r"\n  - \.", md)[1:]:   # one YAML list item per kernel
@@ -103,4 +104,6 @@ def test_no_scratch_and_expected_occupancy(listing):
     enc = meta["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE"]
     assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, enc
     dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi")]
-    assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 64 for d in dec), dec
+    assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 96 and d["lds"] <= 40 * 1024 for d in dec), dec
+    direct = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi0E")]
+    assert direct and all(d["vgpr"] <= 64 for d in direct), direct

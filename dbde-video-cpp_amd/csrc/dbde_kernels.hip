@@ -1240,14 +1240,37 @@ __device__ __forceinline__ uint32_t swz_byte16(uint32_t A) { return A ^ ((A >> 4
 // byte alignment ops (v_alignbyte) instead of 64-bit shifts; the two 4d-bit halves are split
 // with v_alignbit and expanded with v_bfe.  The minimum is added byte-wise with wrap-around, as
 // the reference's _mm_add_epi8 does (dbde_util.cpp:245-277).
+#ifndef DBDE_UNPACK_PLAIN
+// byte k of x <- low byte of (g >> sh): one SDWA shift writes the field where it belongs and leaves the other bytes
+__device__ __forceinline__ void put_byte1(uint32_t &x, uint32_t sh, uint32_t g) {
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(sh), "v"(g));
+}
+__device__ __forceinline__ void put_byte2(uint32_t &x, uint32_t sh, uint32_t g) {
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(sh), "v"(g));
+}
+__device__ __forceinline__ void put_byte3(uint32_t &x, uint32_t sh, uint32_t g) {
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(sh), "v"(g));
+}
+#endif
+
 __device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_img, uint32_t byte_base, uint32_t d,
                                                      uint32_t mn, uint32_t (&v)[16]) {
     const uint32_t mn4 = mn * 0x01010101u;
+    const bool d8 = d >= 8u;
+    uint32_t a = byte_base;
+#ifdef DBDE_UNPACK_PLAIN
     const uint32_t m1 = ((1u << d) - 1u) * 0x00010001u;            // d-bit fields in 16-bit lanes
     const uint32_t m2 = (1u << (2u * d)) - 1u;                     // 2d <= 16
     const uint32_t m4 = d >= 8u ? 0xFFFFFFFFu : ((1u << (4u * d)) - 1u);
-    const bool d8 = d >= 8u;
-    uint32_t a = byte_base;
+#else
+    // four d-bit fields of a 4d-bit group -> the low d bits of four bytes: byte k takes the low byte of (group >> k*d)
+    // (three SDWA shifts), what lies above the field goes with one mask; the minimum is added byte-wise with the
+    // carries cut at bit 7 (add_bytes), the three masks folded into per-tile constants
+    const uint32_t md = ((1u << d) - 1u) * 0x01010101u;            // d = 8: all ones
+    const uint32_t md7 = md & 0x7F7F7F7Fu, mdh = md & 0x80808080u;
+    const uint32_t mnlo = mn4 & 0x7F7F7F7Fu, mnhi = mn4 & 0x80808080u;
+    const uint32_t d2 = 2u * d, d3 = 3u * d;
+#endif
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t A0 = a & ~7u;
@@ -1257,6 +1280,7 @@ __device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_img, uint3
         const uint32_t t0 = up ? lo.y : lo.x, t1 = up ? hi.x : lo.y, t2 = up ? hi.y : hi.x;
         const uint32_t r_lo = __builtin_amdgcn_alignbyte(t1, t0, a);   // bytes [a, a+4)
         const uint32_t r_hi = __builtin_amdgcn_alignbyte(t2, t1, a);   // bytes [a+4, a+8)
+#ifdef DBDE_UNPACK_PLAIN
         const uint32_t g_lo = r_lo & m4;
         const uint32_t g_hi = (d8 ? r_hi : __builtin_amdgcn_alignbit(r_hi, r_lo, 4u * d)) & m4;
         // 4d-bit field -> two 2d-bit fields in 16-bit lanes -> four d-bit fields in bytes
@@ -1266,6 +1290,14 @@ __device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_img, uint3
         const uint32_t y = (f_hi & m1) | (((f_hi >> d) & m1) << 8);
         v[2 * r] = add_bytes(x, mn4);
         v[2 * r + 1] = add_bytes(y, mn4);
+#else
+        const uint32_t g_hi = d8 ? r_hi : __builtin_amdgcn_alignbit(r_hi, r_lo, 4u * d);   // (the shift count is taken modulo 32)
+        uint32_t x = r_lo, y = g_hi;
+        put_byte1(x, d, r_lo); put_byte2(x, d2, r_lo); put_byte3(x, d3, r_lo);
+        put_byte1(y, d, g_hi); put_byte2(y, d2, g_hi); put_byte3(y, d3, g_hi);
+        v[2 * r] = (((x & md7) + mnlo) ^ (x & mdh)) ^ mnhi;
+        v[2 * r + 1] = (((y & md7) + mnlo) ^ (y & mdh)) ^ mnhi;
+#endif
         a += d;
     }
 }

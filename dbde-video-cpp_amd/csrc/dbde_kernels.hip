@@ -343,7 +343,7 @@ constexpr int kEncThreads = 64 * kEncWaves;
 constexpr uint32_t kWaveWords = 128 * 8;                         // 1024 U64 = 8 KiB per wave
 
 struct EncShared {
-    uint64_t pay[kEncWaves][kWaveWords + 64];   // swizzled (swzq8) payload image of each wave + a trash word per lane
+    uint64_t pay[kEncWaves][kWaveWords + 64];   // payload image of each wave (swzq8-swizzled when the wave is all depth 8) + a trash word per lane
     uint32_t tot[2][kEncWaves];              // [parity][wave] payload words of cur per wave
     uint32_t lb[2][4];                       // [parity] {in-frame prefix, launch prefix, ok, next chunk id}
     uint32_t acc[2];                         // [parity] arrivals << 24 | sum of the waves' totals
@@ -491,7 +491,7 @@ __device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, 
     for (int r = 0; r < 8; r++) {
         const uint64_t row = pack_row_dot(v[2 * r] - m4, v[2 * r + 1] - m4, d, w_lo, w_hi, is8);
         const uint64_t merged = acc | (row << fill);
-        pay[swzq8(qq)] = merged;
+        pay[qq] = merged;
         const uint32_t nf = fill + nb;
         const bool emit = nf >= 64u;
         const uint64_t spill = (row >> 1) >> (63u - fill);   // the bits of row beyond the word (0 when fill == 0)
@@ -519,7 +519,7 @@ __device__ __forceinline__ uint64_t frame_base_of(const EncParams &p, uint32_t f
 template <bool ALIGNED_OUT>
 __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkRef &k, uint32_t meta4, uint32_t wbase,
                                                 uint32_t wtot, uint32_t inf, uint32_t glob, const uint64_t *pay,
-                                                int lane) {
+                                                int lane, bool swz) {
     const uint64_t meta = 32ull + 2ull * p.T;
     uint8_t *fb = p.out + frame_base_of(p, k.f, inf, glob);
     uint8_t *depth_arr = fb + 24;
@@ -541,14 +541,14 @@ __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkR
     if (ALIGNED_OUT) {
         const uint32_t q0 = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);   // 1: dst is 8 mod 16
         const uint32_t lead = q0 < wtot ? q0 : wtot;
-        if (lead && lane == 0) *reinterpret_cast<uint64_t *>(dst) = pay[swzq8(0)];
+        if (lead && lane == 0) *reinterpret_cast<uint64_t *>(dst) = pay[0];
         const uint32_t rest = wtot - lead;
         const uint32_t npairs = rest >> 1;
         for (uint32_t i = lane; i < npairs; i += 64u) {
             const uint32_t q = lead + 2u * i;
             ulonglong2 v2;
-            v2.x = pay[swzq8(q)];
-            v2.y = pay[swzq8(q + 1u)];
+            v2.x = pay[swz ? swzq8(q) : q];
+            v2.y = pay[swz ? swzq8(q + 1u) : q + 1u];
             if (DBDE_NT) {
                 u32x4_t o;
                 o[0] = (uint32_t)v2.x; o[1] = (uint32_t)(v2.x >> 32); o[2] = (uint32_t)v2.y; o[3] = (uint32_t)(v2.y >> 32);
@@ -559,10 +559,10 @@ __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkR
         }
         if ((rest & 1u) && lane == 63) {
             const uint32_t q = wtot - 1u;
-            *reinterpret_cast<uint64_t *>(dst + 8ull * q) = pay[swzq8(q)];
+            *reinterpret_cast<uint64_t *>(dst + 8ull * q) = pay[swz ? swzq8(q) : q];
         }
     } else {
-        for (uint32_t q = lane; q < wtot; q += 64u) store_u64_any(dst + 8ull * q, pay[swzq8(q)]);
+        for (uint32_t q = lane; q < wtot; q += 64u) store_u64_any(dst + 8ull * q, pay[swz ? swzq8(q) : q]);
     }
 }
 
@@ -620,6 +620,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     ChunkRef prev = chunk_ref(p, 0xFFFFFFFFu, tid);
     uint64_t *pay = sh.pay[wave];
     uint32_t prev_meta = 0, prev_wbase = 0, prev_wtot = 0, prev_total = 0;
+    bool prev_swz = false;   // prev's payload image is swizzled (its wave was all depth 8)
 #ifdef DBDE_DIAG
     uint64_t dg_wait = 0, dg_nwait = 0, dg_bar = 0, dg_npoll = 0, dg_first = 0;
     const uint64_t dg_k0 = __builtin_amdgcn_s_memtime();
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
 
         // ---- 5. prev: LDS -> global; cur: pack over it (wave-private region) -----------------------
         if (prev.valid) {
-            store_wave_part<ALIGNED_OUT>(p, prev, prev_meta, prev_wbase, prev_wtot, inf, glob, pay, lane);
+            store_wave_part<ALIGNED_OUT>(p, prev, prev_meta, prev_wbase, prev_wtot, inf, glob, pay, lane, prev_swz);
             // what depends only on prefixes -- frame header, the I32 fields, per-frame offset and size -- is
             // written by the workgroup that holds the frame's first / last chunk (one lane, a few stores).  The
             // scanner used to do this; with 64 or fewer chunks per frame it then met a frame boundary in every
@@ -756,9 +757,11 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // all depth 8: lanes write at a 128-byte stride, the image is swizzled; otherwise the offsets are as irregular
+        // as the depths and the swizzle is only address arithmetic (mixed encode 0.68 -> 0.72 without it)
+        const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
         if (wtot != 0u) {
             const uint32_t offA = incl - (dA + dB), offB = offA + dA;
-            const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
             if (all8) {
                 if (cur.hasA) pack_tile_d8(ca, mnA, pay, offA);
                 if (cur.hasB) pack_tile_d8(cb, mnB, pay, offB);
@@ -775,6 +778,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         prev_meta = dA | (dB << 8) | (mnA << 16) | (mnB << 24);
         prev_wbase = wbase;
         prev_wtot = wtot;
+        prev_swz = all8;
         prev_total = cur_total;
         cur = nxt;
         nxt = chunk_ref(p, lb_ok ? next_id : 0xFFFFFFFFu, tid);
@@ -859,9 +863,9 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_small_kernel(EncParams 
     }
     // pack while the record travels (wave-private LDS region, wave-local offsets)
     uint64_t *pay = sh.pay[wave];
+    const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !k.hasA) && (dB == 8u || !k.hasB)));
     if (wtot != 0u) {
         const uint32_t offA = incl - (dA + dB), offB = offA + dA;
-        const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !k.hasA) && (dB == 8u || !k.hasB)));
         if (all8) {
             if (k.hasA) pack_tile_d8(ra, mnA, pay, offA);
             if (k.hasB) pack_tile_d8(rb, mnB, pay, offB);
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_small_kernel(EncParams 
         total += tk;
     }
     if (k.valid && sh.pre[2]) {
-        store_wave_part<ALIGNED_OUT>(p, k, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, glob, pay, lane);
+        store_wave_part<ALIGNED_OUT>(p, k, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, glob, pay, lane, all8);
         if (tid == 64 * (kEncWaves - 1) && (k.cf == 0u || k.cf == p.chunks_per_frame - 1u))
             write_frame_fields<ALIGNED_OUT>(p, k.f, k.cf, inf + total, glob - inf);
     }

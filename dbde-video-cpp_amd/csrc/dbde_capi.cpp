@@ -525,7 +525,7 @@ int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t str
 int dbde_hip_synth_frames(dbde_hip_ctx *ctx, int mode, uint64_t seed, uint64_t first_frame, int n_frames,
                           int W, int H, uint8_t *d_images) {
     if (!ctx) return DBDE_HIP_ERR_ARG;
-    if (!d_images || W <= 0 || H <= 0 || n_frames < 0 || mode < 0 || mode > 3)
+    if (!d_images || W <= 0 || H <= 0 || n_frames < 0 || mode < 0 || mode > 12)
         return fail(ctx, DBDE_HIP_ERR_ARG, "synth_frames: bad argument");
     if (n_frames == 0) return DBDE_HIP_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

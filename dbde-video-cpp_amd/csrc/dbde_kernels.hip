@@ -101,6 +101,9 @@ __device__ __forceinline__ uint32_t swz8(uint32_t slot) { return slot ^ ((slot >
 __device__ __forceinline__ uint32_t swz16(uint32_t slot) { return slot ^ ((slot >> 4) & 15u); }    // 256-B groups
 // qword index -> swizzled qword index (the half inside the slot is kept)
 __device__ __forceinline__ uint32_t swzq8(uint32_t q) { return (swz8(q >> 1) << 1) | (q & 1u); }
+#ifndef DBDE_ENC_SWZ_ALL
+#define DBDE_ENC_SWZ_ALL 0   // A/B switch: 1 = the encoder's payload image swizzled for every wave (round-2 start)
+#endif
 __device__ __forceinline__ uint32_t swzq16(uint32_t q) { return (swz16(q >> 1) << 1) | (q & 1u); }
 
 // Any of the four depth bytes of x above the format's maximum (8, or 16 for DBDE16)?  Non-zero if so.
@@ -491,7 +494,7 @@ __device__ __forceinline__ void pack_tile(const uint32_t (&v)[16], uint32_t mn, 
     for (int r = 0; r < 8; r++) {
         const uint64_t row = pack_row_dot(v[2 * r] - m4, v[2 * r + 1] - m4, d, w_lo, w_hi, is8);
         const uint64_t merged = acc | (row << fill);
-        pay[qq] = merged;
+        pay[DBDE_ENC_SWZ_ALL ? swzq8(qq) : qq] = merged;
         const uint32_t nf = fill + nb;
         const bool emit = nf >= 64u;
         const uint64_t spill = (row >> 1) >> (63u - fill);   // the bits of row beyond the word (0 when fill == 0)
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         prev_meta = dA | (dB << 8) | (mnA << 16) | (mnB << 24);
         prev_wbase = wbase;
         prev_wtot = wtot;
-        prev_swz = all8;
+        prev_swz = all8 || DBDE_ENC_SWZ_ALL;
         prev_total = cur_total;
         cur = nxt;
         nxt = chunk_ref(p, lb_ok ? next_id : 0xFFFFFFFFu, tid);
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_small_kernel(EncParams 
         total += tk;
     }
     if (k.valid && sh.pre[2]) {
-        store_wave_part<ALIGNED_OUT>(p, k, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, glob, pay, lane, all8);
+        store_wave_part<ALIGNED_OUT>(p, k, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, glob, pay, lane, all8 || DBDE_ENC_SWZ_ALL);
         if (tid == 64 * (kEncWaves - 1) && (k.cf == 0u || k.cf == p.chunks_per_frame - 1u))
             write_frame_fields<ALIGNED_OUT>(p, k.f, k.cf, inf + total, glob - inf);
     }
@@ -1244,6 +1247,12 @@ __device__ __forceinline__ uint32_t swz_byte16(uint32_t A) { return A ^ ((A >> 4
 // byte alignment ops (v_alignbyte) instead of 64-bit shifts; the two 4d-bit halves are split
 // with v_alignbit and expanded with v_bfe.  The minimum is added byte-wise with wrap-around, as
 // the reference's _mm_add_epi8 does (dbde_util.cpp:245-277).
+#ifndef DBDE_DEC_SWZ_ALL
+#define DBDE_DEC_SWZ_ALL 0   // A/B switch: 1 = the decoder's payload image swizzled for every chunk (round-2 start)
+#endif
+#ifndef DBDE_DEC_SWZ_REGULAR
+#define DBDE_DEC_SWZ_REGULAR 1   // A/B switch: 0 = swizzle for all-depth-8 chunks only
+#endif
 #ifndef DBDE_UNPACK_PLAIN
 // byte k of x <- low byte of (g >> sh): one SDWA shift writes the field where it belongs and leaves the other bytes
 __device__ __forceinline__ void put_byte1(uint32_t &x, uint32_t sh, uint32_t g) {
@@ -1257,6 +1266,7 @@ __device__ __forceinline__ void put_byte3(uint32_t &x, uint32_t sh, uint32_t g) 
 }
 #endif
 
+template <bool SWZ>
 __device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_img, uint32_t byte_base, uint32_t d,
                                                      uint32_t mn, uint32_t (&v)[16]) {
     const uint32_t mn4 = mn * 0x01010101u;
@@ -1278,8 +1288,8 @@ __device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_img, uint3
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t A0 = a & ~7u;
-        const uint2 lo = *reinterpret_cast<const uint2 *>(s_img + swz_byte16(A0));
-        const uint2 hi = *reinterpret_cast<const uint2 *>(s_img + swz_byte16(A0 + 8u));
+        const uint2 lo = *reinterpret_cast<const uint2 *>(s_img + (SWZ ? swz_byte16(A0) : A0));
+        const uint2 hi = *reinterpret_cast<const uint2 *>(s_img + (SWZ ? swz_byte16(A0 + 8u) : A0 + 8u));
         const bool up = (a & 4u) != 0u;
         const uint32_t t0 = up ? lo.y : lo.x, t1 = up ? hi.x : lo.y, t2 = up ? hi.y : hi.x;
         const uint32_t r_lo = __builtin_amdgcn_alignbyte(t1, t0, a);   // bytes [a, a+4)
@@ -1550,6 +1560,13 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     // LDS-DMA (global_load_lds_dwordx4): physical slot i of the image <- logical slot swz16(i)
     // of the stream; the destination is wave-uniform base + lane*16, the permutation stays
     // inside one 256-byte group so the source side remains coalesced.  No staging registers.
+    // The image is swizzled only for chunks whose lanes would read it at a regular stride that piles onto few banks:
+    // every tile of depth 8 (128 bytes per lane), 4 (64: -11 % unswizzled, measured) or 7 -- the chunk's word count
+    // says so before a single depth byte has arrived (a mixed chunk that happens to average 4 or 7 is swizzled for
+    // nothing, that is all).  Any other chunk is read at offsets as irregular as its depths, or at strides that
+    // measured no slower, and the swizzle would only be address arithmetic in the unpack (6 VALU per tile row:
+    // mixed 0.75 -> 0.78, uniform depth 2 / 3 0.72 / 0.75 -> 0.77 / 0.78).
+    const bool swz = DBDE_DEC_SWZ_ALL || chunk_words == 8u * n_tiles || (DBDE_DEC_SWZ_REGULAR && (chunk_words == 4u * n_tiles || chunk_words == 7u * n_tiles));
     const uint32_t n16r = (n16 + 15u) & ~15u;
     // Never read past the extent the caller declared (dbde_hip.h: stream_bytes is the READABLE extent): the
     // whole-slot DMA stops before a slot that straddles the end; that slot (the last one of the last chunk
@@ -1559,7 +1576,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
 #pragma unroll
     for (int j = 0; j < G::kPieces; j++) {
         const uint32_t i = (uint32_t)tid + (uint32_t)j * G::kThreads;
-        const uint32_t src_slot = swz16(i);
+        const uint32_t src_slot = swz ? swz16(i) : i;
         if (i < n16r && src_slot < n16_dma) {
             const uint32_t wave_slot0 = (uint32_t)j * G::kThreads + (uint32_t)wave * 64u;
             __builtin_amdgcn_global_load_lds(
@@ -1569,7 +1586,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     }
     if (n16_dma != n16 && tid < 16) {   // the straddling slot, byte by byte: logical slot L lives at physical swz16(L)
         const uint8_t *b = asrc + 16ull * n16_dma + (uint32_t)tid;
-        reinterpret_cast<uint8_t *>(s_in)[16u * swz16(n16_dma) + (uint32_t)tid] = b < s_end ? *b : (uint8_t)0;
+        reinterpret_cast<uint8_t *>(s_in)[16u * (swz ? swz16(n16_dma) : n16_dma) + (uint32_t)tid] = b < s_end ? *b : (uint8_t)0;
     }
     uint32_t dA = 0, dB = 0, mA = 0, mB = 0;
     // the lane's two tiles are one u16 load per array where that address is even
@@ -1595,7 +1612,8 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     const uint8_t *s_img = reinterpret_cast<const uint8_t *>(s_in);
     const uint32_t bA = shift + 8u * offA, bB = shift + 8u * offB;
     // wave-uniform specialisations: all tiles flat (depth 0), or all of depth 8 (rows are whole qwords)
-    const bool all8 = (shift & 7u) == 0u && __all((int)(dA == 8u && dB == 8u));
+    // all of depth 8, rows whole qwords (lanes without a tile read 64 bytes of slack behind the image and store nothing)
+    const bool all8 = swz && (shift & 7u) == 0u && __all((int)((dA == 8u || !hasA) && (dB == 8u || !hasB)));
     const bool flat = __all((int)((dA | dB) == 0u));
     if (flat) {   // flat tiles only: every pixel is its tile's minimum, no payload
 #pragma unroll
@@ -1604,8 +1622,13 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         unpack_tile_d8_from_lds(s_img, bA, mA, va);
         unpack_tile_d8_from_lds(s_img, bB, mB, vb);
     } else {
-        unpack_tile_from_lds(s_img, bA, dA, mA, va);
-        unpack_tile_from_lds(s_img, bB, dB, mB, vb);
+        if (swz) {
+            unpack_tile_from_lds<true>(s_img, bA, dA, mA, va);
+            unpack_tile_from_lds<true>(s_img, bB, dB, mB, vb);
+        } else {
+            unpack_tile_from_lds<false>(s_img, bA, dA, mA, va);
+            unpack_tile_from_lds<false>(s_img, bB, dB, mB, vb);
+        }
     }
 
     uint8_t *img = p.images + (size_t)f * p.frame_pixels;
@@ -2006,6 +2029,16 @@ __global__ __launch_bounds__(256) void synth_kernel(int mode, uint64_t seed, uin
             }
         } else if (mode == 2) {
             out = (seed & 0xFFull) * 0x0101010101010101ull;
+        } else if (mode >= 4) {   // every tile of depth mode - 4 (0..8): the regular lane strides of uniform content
+            const uint32_t d = (uint32_t)(mode - 4) > 8u ? 8u : (uint32_t)(mode - 4);
+            const uint32_t top = (1u << d) - 1u, m = 100u > 255u - top ? 255u - top : 100u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t pix = m + ((uint32_t)(rk >> (8 * k)) & top);
+                if ((y & 7u) == 0u && k == 0) pix = m;
+                if ((y & 7u) == 0u && k == 1) pix = m + top;
+                out |= (uint64_t)(pix & 0xFFu) << (8 * k);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 8; k++) {

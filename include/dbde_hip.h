@@ -141,7 +141,8 @@ int dbde_hip_scan_ahead(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t strea
 int dbde_hip_scan_join(dbde_hip_ctx *ctx);
 
 /* Counter-based synthetic frames (same bytes as oracle/synth.c): mode 0 noise8, 1 mixed,
- * 2 flat, 3 smooth.  Used by bench.py and the parity tests to build inputs in HBM. */
+ * 2 flat, 3 smooth; modes 4..12 (profiling only, no oracle twin): every tile of depth mode - 4.
+ * Used by bench.py and the parity tests to build inputs in HBM. */
 int dbde_hip_synth_frames(dbde_hip_ctx *ctx, int mode, uint64_t seed, uint64_t first_frame,
                           int n_frames, int W, int H, uint8_t *d_images);
 

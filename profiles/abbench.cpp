@@ -1,7 +1,7 @@
 // abbench.cpp -- A/B timing of libdbde_hip.so builds through the C-ABI, without Python (no torch import:
 // a variant costs seconds, so one GPU call can rank many).  Build: hipcc --offload-arch=gfx950 -O2
 // profiles/abbench.cpp -o profiles/abbench -ldl.  Usage:
-//   abbench <libdbde_hip.so> <W> <H> <frames> <noise8|mixed|flat|smooth> <slots|concat> <steps> [tag]
+//   abbench <libdbde_hip.so> <W> <H> <frames> <noise8|mixed|flat|smooth|depthN> <slots|concat> <steps> [tag]
 // Prints one JSON line: kernel times from the library's own HIP-event hook, round trip verified on the device.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -36,6 +36,7 @@ int main(int argc, char **argv) {
     const bool slots = strcmp(argv[6], "slots") == 0;
     const char *tag = argc > 8 ? argv[8] : libpath;
     int mode = !strcmp(content, "noise8") ? 0 : !strcmp(content, "mixed") ? 1 : !strcmp(content, "flat") ? 2 : 3;
+    if (!strncmp(content, "depth", 5)) mode = 4 + atoi(content + 5);   // every tile of that depth
     void *h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
     using fn_dbde_hip_create = int (*)(int, void *, ctx **);

@@ -94,7 +94,7 @@ def test_fast_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing, mangl
 def test_no_scratch_and_expected_occupancy(listing):
     """The hot kernels must not spill and must keep the residency the design assumes: encoder <= 128 VGPRs
     (2 workgroups of 8 waves per CU); decoder: LDS (<= 40 KB) allows 4 workgroups = 4 waves per SIMD, registers must
-    not be what limits it (<= 96 leaves a fifth wave; the direct-image instances stay <= 64)."""
+    not be what limits it (<= 96 leaves a fifth wave)."""
     meta = {}
     md = listing[listing.index("amdhsa.kernels:"):]
     for entry in re.split(r"\n  - \.", md)[1:]:   # one YAML list item per kernel
@@ -105,5 +105,3 @@ def test_no_scratch_and_expected_occupancy(listing):
     assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, enc
     dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi")]
     assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 96 and d["lds"] <= 40 * 1024 for d in dec), dec
-    direct = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi0E")]
-    assert direct and all(d["vgpr"] <= 64 for d in direct), direct

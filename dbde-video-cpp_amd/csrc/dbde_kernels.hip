@@ -1287,11 +1287,17 @@ __device__ __forceinline__ void unpack_tile_from_lds(const uint8_t *s_img, uint3
 #endif
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const uint32_t A0 = a & ~7u;
-        const uint2 lo = *reinterpret_cast<const uint2 *>(s_img + (SWZ ? swz_byte16(A0) : A0));
-        const uint2 hi = *reinterpret_cast<const uint2 *>(s_img + (SWZ ? swz_byte16(A0 + 8u) : A0 + 8u));
-        const bool up = (a & 4u) != 0u;
-        const uint32_t t0 = up ? lo.y : lo.x, t1 = up ? hi.x : lo.y, t2 = up ? hi.y : hi.x;
+        uint32_t t0, t1, t2;   // the three dwords that hold bytes [a, a+8)
+        if (SWZ) {             // 16-byte slots are permuted: the two enclosing qwords, then the right three of four
+            const uint32_t A0 = a & ~7u;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(s_img + swz_byte16(A0));
+            const uint2 hi = *reinterpret_cast<const uint2 *>(s_img + swz_byte16(A0 + 8u));
+            const bool up = (a & 4u) != 0u;
+            t0 = up ? lo.y : lo.x; t1 = up ? hi.x : lo.y; t2 = up ? hi.y : hi.x;
+        } else {               // linear image: straight from the dword address
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(s_img + (a & ~3u));
+            t0 = q[0]; t1 = q[1]; t2 = q[2];
+        }
         const uint32_t r_lo = __builtin_amdgcn_alignbyte(t1, t0, a);   // bytes [a, a+4)
         const uint32_t r_hi = __builtin_amdgcn_alignbyte(t2, t1, a);   // bytes [a+4, a+8)
 #ifdef DBDE_UNPACK_PLAIN

@@ -25,7 +25,7 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 codec, ora = dv.Codec(0), Oracle()
-shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080)]
+shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080), (1001, 999), (1366, 768), (641, 481), (1928, 1080)]
 t0 = time.time()
 frames_done = 0
 for r in range(a.rounds):

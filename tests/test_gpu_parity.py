@@ -371,6 +371,29 @@ def test_decode_staged_rows_off_alignment(codec, oracle, W, H):
                 assert r == (2, 5 + f, 0, len(packed[f]))
 
 
+@pytest.mark.parametrize("d", range(9))
+def test_uniform_depth_content(codec, oracle, d):
+    """Every tile of one depth (synth modes 4..12): the regular lane strides the LDS swizzles exist for, and the only
+    content that reaches the decoder's swizzled general unpack (chunks whose word count is 4 or 7 per tile).  Encoder
+    bytes against the oracle, depth array as promised, decode back, misaligned stream included."""
+    import torch
+    for (W, H, n) in [(4096, 16, 3), (1024, 40, 2), (1921, 17, 2), (200, 123, 2)]:
+        imgs = codec.synth_frames(4 + d, SEED, 11, n, W, H)
+        imgs_h = imgs.cpu().numpy()
+        T = ((W + 7) // 8) * ((H + 7) // 8)
+        for misalign in (0, 3):
+            frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=11, misalign=misalign)
+            for f in range(n):
+                want = oracle.pack_frame(11 + f, imgs_h[f], W, H)
+                assert frames[f].tobytes() == want.tobytes(), (d, W, H, misalign, f)
+                if W % 8 == 0 and H % 8 == 0:   # (partial tiles may miss the two pixels that pin the range)
+                    assert (frames[f][24: 24 + T] == d).all(), (d, W, H, "depth array")
+            total = int((offs[-1] + sizes[-1]).item())
+            back, res = codec.decode_frames(buf, lead, total, offs, W, H, n)
+            codec.sync()
+            assert torch.equal(back, imgs), (d, W, H, misalign)
+
+
 @pytest.mark.parametrize("name", ["cfg2_4096x3072", "cfg3_2048x2048", "cfg4_1921x1081"])
 def test_baseline_configs_full_size(codec, golden, name):
     """BASELINE.json configs 2-4: packed-frame hashes equal the REAL reference's (fixtures)."""

@@ -25,7 +25,8 @@ struct Params16 {                   // encode
     unsigned long long *gsum;       // [n_frames * ceil(cpf / 64)] words of a frame's group of 64 chunks
     unsigned long long *fsize;      // [n_frames] words of a frame (concatenated layout)
     unsigned long long *fgsum;      // [ceil(n_frames / 64)] words of a group of 64 frames (concatenated layout)
-    uint32_t *ticket;               // chunk ids are arrival tickets
+    uint32_t *ticket;               // [0] arrival / ticket counter, [1] how chunk ids are claimed (0 undecided, 1 static, 2 tickets)
+    uint32_t force_tickets;         // tests: skip the static assignment
     uint32_t *sticky;               // context-wide failure word, OR-ed on a look-back time-out
     unsigned long long *diag;       // -DDBDE_DIAG builds: phase time sums ([0..7], 10 ns ticks), else unused
 };
@@ -43,7 +44,8 @@ struct DecParams16 {
     unsigned long long *diag;       // -DDBDE_DIAG builds only
 };
 
-hipError_t launch_encode16(const Params16 &p, int n_frames, hipStream_t s);
+int encode16_blocks_per_cu();   // resident workgroups per CU of the persistent encoder (occupancy query)
+hipError_t launch_encode16(const Params16 &p, int n_frames, uint32_t resident_blocks, hipStream_t s);
 hipError_t launch_decode16(const DecParams16 &p, int n_frames, hipStream_t s);
 
 }  // namespace dbde16

@@ -127,154 +127,212 @@ __device__ __forceinline__ uint32_t sum_records(const u64a *r0, uint32_t n0, con
     return 1u;
 }
 
-__global__ __launch_bounds__(kChunkTiles16) void enc16_kernel(Params16 p) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kChunkTiles16 * 16 + kChunkTiles16];   // 16 words per tile + a trash word per lane
-    __shared__ uint32_t s_tot[kChunkTiles16 / 64];
-    __shared__ uint32_t s_chunk, s_ok;
-    __shared__ unsigned long long s_pre[2];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-#ifdef DBDE_DIAG
-    uint64_t dt[6]; dt[0] = wall_clock64();
-#define DIAG_MARK(i) dt[i] = wall_clock64()
-#else
-#define DIAG_MARK(i)
-#endif
-    if (tid == 0) s_chunk = atomicAdd(p.ticket, 1u);
-    __syncthreads();
-    const uint32_t c = __builtin_amdgcn_readfirstlane(s_chunk);
-    DIAG_MARK(1);
-    const Tile16 k = tile_of(p, c, tid);
-    uint32_t v[32];
-    load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
-    uint32_t mn, mx;
-    tile_minmax16(v, mn, mx);
-    const uint32_t d = k.has ? depth_of(mx - mn) : 0u;
-    const uint32_t incl = wave_scan_incl(d);
-    if (lane == 63u) s_tot[wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) { wbase += q < wave ? s_tot[q] : 0u; total += s_tot[q]; }
-    if (tid == 0) __hip_atomic_store(&p.state[c], kReady | (u64a)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    DIAG_MARK(2);
+// LDS payload image of a chunk: kPayWords16 words + one shared trash word.  The worst case (256 tiles of depth 16) is
+// what it holds today -- registers (the persistent loop needs ~120) limit the kernel to four workgroups per CU anyway;
+// a fifth would need <= 32,768 bytes of LDS and 96 registers (tried: 27 spills, 1.51 ms against 1.20 ms).  A smaller
+// image works too: a chunk with more words stores the first kPayWords16, then packs again for the rest (tested with
+// kPayWords16 = 4088; pack_tile16 / the second pass below are written for any value).
+constexpr uint32_t kPayWords16 = kChunkTiles16 * 16u;
 
-    // pack while the record travels: straight-line funnel over 16 half rows of 4*d <= 64 bits (every half row
-    // stores the word it is filling; a tile without payload stores into the lane's trash word)
+// The tile's payload words into the LDS image: straight-line funnel over 16 half rows of 4*d <= 64 bits (every half
+// row stores the word it is filling).  Words [q_lo, q_lo + kPayWords16) of the chunk go to image[0..), the others and
+// everything of a tile without payload to the trash word.
+__device__ __forceinline__ void pack_tile16(const uint32_t (&v)[32], uint32_t mn, uint32_t d, uint64_t *s_pay, uint32_t q0, uint32_t q_lo) {
     const uint32_t mn2 = mn * 0x00010001u;   // every 16-bit half >= mn: no borrow crosses a half
     const uint32_t nb = 4u * d;
-    uint32_t q = d ? wbase + incl - d : kChunkTiles16 * 16u + tid;
+    uint32_t q = d ? q0 - q_lo : kPayWords16;   // (unsigned: words in front of q_lo wrap to huge and land in the trash)
     uint64_t acc = 0;
     uint32_t fill = 0;
 #pragma unroll
     for (int h = 0; h < 16; h++) {
         const uint64_t bits = pack4x16(v[2 * h] - mn2, v[2 * h + 1] - mn2, d);
         const uint64_t merged = acc | (bits << fill);
-        s_pay[q] = merged;
+        s_pay[q < kPayWords16 ? q : kPayWords16] = merged;
         const uint32_t nf = fill + nb;
         const bool emit = nf >= 64u;
         acc = emit ? ((bits >> 1) >> (63u - fill)) : merged;
         fill = nf & 63u;
         q += emit ? 1u : 0u;
     }
+}
 
-    // Prefix inside the frame and the frame's base WITHOUT a serial chain: two-level sums of records that each depend
-    // on published counts only.  A = the chunks in front of this one in its group of 64, B = the frame's groups in
-    // front (a group's count is published by its 64th chunk = A + own), C / D = the same two levels over frame word
-    // counts (concatenated layout; a frame's count is published by its last chunk).  One poll of four loads per lane.
-    const uint64_t meta = 32ull + 3ull * p.T;
-    DIAG_MARK(3);
-    if (wave == 0) {
-        const uint64_t t_start = wall_clock64();
-        const uint32_t g = k.cf >> 6, nA = k.cf & 63u, gpf = (p.chunks_per_frame + 63u) >> 6;
-        const bool concat = p.slot_stride == 0ull;
-        const uint32_t nC = concat ? (k.f & 63u) : 0u, fg = concat ? (k.f >> 6) : 0u;
-        const u64a *rA = p.state + (size_t)k.f * p.chunks_per_frame + (size_t)g * 64u;
-        const u64a *rB = p.gsum + (size_t)k.f * gpf;
-        const u64a *rC = p.fsize + (size_t)(k.f & ~63u);
-        uint64_t sA = 0, sB = 0, sC = 0, sD = 0, z0, z1, z2;
-        uint32_t ok = 1u;
-        const uint32_t nB = g < 64u ? g : 64u, nD = fg < 64u ? fg : 64u;
-        const bool pub_group = nA == 63u, pub_frame = concat && k.cf == p.chunks_per_frame - 1u;
-        if (!pub_group && !pub_frame) {
-            ok = sum_records(rA, nA, rB, nB, rC, nC, p.fgsum, nD, lane, t_start, sA, sB, sC, sD);
-        } else {   // a chunk that publishes a higher-level record does so BEFORE it waits for records of that level
-            ok = sum_records(rA, nA, rA, 0u, rA, 0u, rA, 0u, lane, t_start, sA, z0, z1, z2);
-            if (pub_group && lane == 0 && ok)
-                __hip_atomic_store(&p.gsum[(size_t)k.f * gpf + g], kReady | (u64a)(sA + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ok) ok = sum_records(rB, nB, rC, nC, rA, 0u, rA, 0u, lane, t_start, sB, sC, z0, z1);
-        }
-        for (uint32_t i = 64u; i < g && ok; i += 64u) {    // frames of more than 4096 chunks
-            uint64_t x = 0;
-            ok = sum_records(rB + i, g - i < 64u ? g - i : 64u, rA, 0u, rA, 0u, rA, 0u, lane, t_start, x, z0, z1, z2);
-            sB += x;
-        }
-        const uint64_t inf = sA + sB, fwords = inf + total;
-        if (pub_frame && lane == 0 && ok) {
-            __hip_atomic_store(&p.fsize[k.f], kReady | (u64a)fwords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (nC == 63u) __hip_atomic_store(&p.fgsum[fg], kReady | (u64a)(sC + fwords), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if ((pub_group || pub_frame) && ok) ok = sum_records(p.fgsum, nD, rA, 0u, rA, 0u, rA, 0u, lane, t_start, sD, z0, z1, z2);
-        for (uint32_t i = 64u; i < fg && ok; i += 64u) {   // launches of more than 4096 frames
-            uint64_t x = 0;
-            ok = sum_records(p.fgsum + i, fg - i < 64u ? fg - i : 64u, rA, 0u, rA, 0u, rA, 0u, lane, t_start, x, z0, z1, z2);
-            sD += x;
-        }
-        if (lane == 0) {
-            s_pre[0] = inf;
-            s_pre[1] = concat ? (uint64_t)k.f * meta + 8ull * (sC + sD) : (uint64_t)k.f * p.slot_stride;
-            s_ok = ok;
-            if (!ok) atomicOr(p.sticky, 1u);
-        }
-    }
-    DIAG_MARK(4);
-    __syncthreads();
-    if (!s_ok) return;
-    DIAG_MARK(5);
-    const uint32_t inf = (uint32_t)s_pre[0];
-    uint8_t *fb = p.out + s_pre[1];
-    if (k.has) {   // metadata of this lane's tile
-        fb[24 + k.t] = (uint8_t)d;
-        uint8_t *m = fb + 28 + p.T + 2ull * k.t;
-        m[0] = (uint8_t)mn; m[1] = (uint8_t)(mn >> 8);
-    }
-    uint8_t *dst = fb + meta + 8ull * inf;   // the chunk's contiguous payload
-    if ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0u) {   // word-aligned: 16-byte stores between a possible odd first and last word
+// `n` words of the LDS image to dst (the chunk's payload is contiguous): 16-byte stores where dst is word-aligned.
+__device__ __forceinline__ void copy_out16(const uint64_t *s_pay, uint8_t *dst, uint32_t n, uint32_t tid) {
+    if ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0u) {   // 16-byte stores between a possible odd first and last word
         const uint32_t head = (uint32_t)(reinterpret_cast<uintptr_t>(dst) >> 3) & 1u;
-        const uint32_t h1 = head < total ? head : total;
+        const uint32_t h1 = head < n ? head : n;
         if (tid == 0 && h1) *reinterpret_cast<uint64_t *>(dst) = s_pay[0];
-        const uint32_t pairs = (total - h1) >> 1;
+        const uint32_t pairs = (n - h1) >> 1;
         typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
         for (uint32_t i = tid; i < pairs; i += kChunkTiles16) {
             u64x2_t q = {s_pay[h1 + 2u * i], s_pay[h1 + 2u * i + 1u]};
             *reinterpret_cast<u64x2_t *>(dst + 8ull * (h1 + 2u * i)) = q;
         }
-        if (tid == 64u && ((total - h1) & 1u)) *reinterpret_cast<uint64_t *>(dst + 8ull * (total - 1u)) = s_pay[total - 1u];
+        if (tid == 64u && ((n - h1) & 1u)) *reinterpret_cast<uint64_t *>(dst + 8ull * (n - 1u)) = s_pay[n - 1u];
     } else {
-        for (uint32_t i = tid; i < total; i += kChunkTiles16) store_u64_any(dst + 8ull * i, s_pay[i]);
+        for (uint32_t i = tid; i < n; i += kChunkTiles16) store_u64_any(dst + 8ull * i, s_pay[i]);
     }
-    if (tid == 0) {
-        if (k.cf == 0u) {   // frame header and the first I32 fields (trap T1: elapsed travels as an F64; 0 here)
-            store_u32_bytes(fb, 2u);
-            store_u64_any(fb + 4, p.first_index + k.f);
-            store_u64_any(fb + 12, 0ull);
-            store_u32_bytes(fb + 20, p.T);
-            store_u32_bytes(fb + 24 + p.T, 2u * p.T);
-            if (p.frame_offsets) p.frame_offsets[k.f] = s_pre[1];
-        }
-        if (k.cf == p.chunks_per_frame - 1u) {   // the frame's word count is known here
-            const uint32_t words = inf + total;
-            store_u32_bytes(fb + 28 + 3ull * p.T, words);
-            if (p.frame_bytes) p.frame_bytes[k.f] = meta + 8ull * words;
-        }
-    }
-#ifdef DBDE_DIAG
-    if (tid == 0 && (c & 63u) == 5u) {   // a sample of workgroups, wave 0's view: ticket | load+reduce | pack | look-back | barrier wait | store
-        __builtin_amdgcn_s_waitcnt(0);
-        const uint64_t t6 = wall_clock64();
-        for (int i = 0; i < 5; i++) atomicAdd(&p.diag[i], (unsigned long long)(dt[i + 1] - dt[i]));
-        atomicAdd(&p.diag[5], (unsigned long long)(t6 - dt[5]));
-        atomicAdd(&p.diag[6], 1ull);
-    }
+}
+
+#ifndef DBDE16_WAVES
+#define DBDE16_WAVES 4
 #endif
+__global__ __launch_bounds__(kChunkTiles16, DBDE16_WAVES) void enc16_kernel(Params16 p) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kPayWords16 + 1];   // + the trash word
+    __shared__ uint32_t s_tot[kChunkTiles16 / 64];
+    __shared__ uint32_t s_chunk, s_ok, s_boot[2];
+    __shared__ unsigned long long s_pre[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef DBDE_DIAG
+    uint64_t dt[6];
+#define DIAG_MARK(i) dt[i] = wall_clock64()
+#else
+#define DIAG_MARK(i)
+#endif
+    // Chunk ids.  A workgroup's first chunk is its arrival rank.  STATIC (chunk = rank + k * G, no atomic per chunk: a
+    // single-address ticket per 256-tile chunk caps the launch at about 73 chunks per microsecond and costs 2 us of
+    // every chunk's life, measured) is only safe when all G workgroups run at the same time; that is proven, not
+    // assumed: all G have arrived before anyone left.  If the arrivals do not complete within 20 us the launch
+    // falls back to TICKETS (the arrival counter keeps counting, ids stay dense), which needs nothing but running
+    // workgroups.  One CAS decides for the whole launch.
+    const uint32_t n_chunks = p.n_frames * p.chunks_per_frame, G = gridDim.x;
+    if (tid == 0) {
+        const uint32_t rank = atomicAdd(&p.ticket[0], 1u);
+        uint32_t mode = n_chunks <= G ? 1u : 0u;   // one chunk per workgroup at most: nothing to agree on
+        const uint64_t t0 = wall_clock64();
+        while (!mode) {
+            mode = __hip_atomic_load(&p.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mode) break;
+            const uint32_t arrived = __hip_atomic_load(&p.ticket[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived >= G && !p.force_tickets) atomicCAS(&p.ticket[1], 0u, 1u);
+            else if (p.force_tickets || wall_clock64() - t0 > 2000ull) atomicCAS(&p.ticket[1], 0u, 2u);
+            else __builtin_amdgcn_s_sleep(2);
+        }
+        s_boot[0] = rank; s_boot[1] = mode;
+    }
+    __syncthreads();
+    const bool static_mode = __builtin_amdgcn_readfirstlane(s_boot[1]) == 1u;
+    uint32_t c = __builtin_amdgcn_readfirstlane(s_boot[0]);
+    while (c < n_chunks) {
+#ifdef DBDE_DIAG
+        dt[0] = wall_clock64();
+#endif
+        DIAG_MARK(1);
+        const Tile16 k = tile_of(p, c, tid);
+        uint32_t v[32];
+        load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
+        uint32_t mn, mx;
+        tile_minmax16(v, mn, mx);
+        const uint32_t d = k.has ? depth_of(mx - mn) : 0u;
+        const uint32_t incl = wave_scan_incl(d);
+        if (lane == 63u) s_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+        for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) { wbase += q < wave ? s_tot[q] : 0u; total += s_tot[q]; }
+        if (tid == 0) __hip_atomic_store(&p.state[c], kReady | (u64a)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DIAG_MARK(2);
+
+        // pack while the record travels
+        pack_tile16(v, mn, d, s_pay, wbase + incl - d, 0u);
+
+        // Prefix inside the frame and the frame's base WITHOUT a serial chain: two-level sums of records that each depend
+        // on published counts only.  A = the chunks in front of this one in its group of 64, B = the frame's groups in
+        // front (a group's count is published by its 64th chunk = A + own), C / D = the same two levels over frame word
+        // counts (concatenated layout; a frame's count is published by its last chunk).  One poll of four loads per lane.
+        const uint64_t meta = 32ull + 3ull * p.T;
+        DIAG_MARK(3);
+        if (wave == 0) {
+            const uint64_t t_start = wall_clock64();
+            const uint32_t g = k.cf >> 6, nA = k.cf & 63u, gpf = (p.chunks_per_frame + 63u) >> 6;
+            const bool concat = p.slot_stride == 0ull;
+            const uint32_t nC = concat ? (k.f & 63u) : 0u, fg = concat ? (k.f >> 6) : 0u;
+            const u64a *rA = p.state + (size_t)k.f * p.chunks_per_frame + (size_t)g * 64u;
+            const u64a *rB = p.gsum + (size_t)k.f * gpf;
+            const u64a *rC = p.fsize + (size_t)(k.f & ~63u);
+            uint64_t sA = 0, sB = 0, sC = 0, sD = 0, z0, z1, z2;
+            uint32_t ok = 1u;
+            const uint32_t nB = g < 64u ? g : 64u, nD = fg < 64u ? fg : 64u;
+            const bool pub_group = nA == 63u, pub_frame = concat && k.cf == p.chunks_per_frame - 1u;
+            if (!pub_group && !pub_frame) {
+                ok = sum_records(rA, nA, rB, nB, rC, nC, p.fgsum, nD, lane, t_start, sA, sB, sC, sD);
+            } else {   // a chunk that publishes a higher-level record does so BEFORE it waits for records of that level
+                ok = sum_records(rA, nA, rA, 0u, rA, 0u, rA, 0u, lane, t_start, sA, z0, z1, z2);
+                if (pub_group && lane == 0 && ok)
+                    __hip_atomic_store(&p.gsum[(size_t)k.f * gpf + g], kReady | (u64a)(sA + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ok) ok = sum_records(rB, nB, rC, nC, rA, 0u, rA, 0u, lane, t_start, sB, sC, z0, z1);
+            }
+            for (uint32_t i = 64u; i < g && ok; i += 64u) {    // frames of more than 4096 chunks
+                uint64_t x = 0;
+                ok = sum_records(rB + i, g - i < 64u ? g - i : 64u, rA, 0u, rA, 0u, rA, 0u, lane, t_start, x, z0, z1, z2);
+                sB += x;
+            }
+            const uint64_t inf = sA + sB, fwords = inf + total;
+            if (pub_frame && lane == 0 && ok) {
+                __hip_atomic_store(&p.fsize[k.f], kReady | (u64a)fwords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (nC == 63u) __hip_atomic_store(&p.fgsum[fg], kReady | (u64a)(sC + fwords), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if ((pub_group || pub_frame) && ok) ok = sum_records(p.fgsum, nD, rA, 0u, rA, 0u, rA, 0u, lane, t_start, sD, z0, z1, z2);
+            for (uint32_t i = 64u; i < fg && ok; i += 64u) {   // launches of more than 4096 frames
+                uint64_t x = 0;
+                ok = sum_records(p.fgsum + i, fg - i < 64u ? fg - i : 64u, rA, 0u, rA, 0u, rA, 0u, lane, t_start, x, z0, z1, z2);
+                sD += x;
+            }
+            if (lane == 0) {
+                s_pre[0] = inf;
+                s_pre[1] = concat ? (uint64_t)k.f * meta + 8ull * (sC + sD) : (uint64_t)k.f * p.slot_stride;
+                s_ok = ok;
+                if (!ok) atomicOr(p.sticky, 1u);
+            }
+        }
+        DIAG_MARK(4);
+        __syncthreads();
+        if (!s_ok) return;
+        DIAG_MARK(5);
+        const uint32_t inf = (uint32_t)s_pre[0];
+        uint8_t *fb = p.out + s_pre[1];
+        if (k.has) {   // metadata of this lane's tile
+            fb[24 + k.t] = (uint8_t)d;
+            uint8_t *m = fb + 28 + p.T + 2ull * k.t;
+            m[0] = (uint8_t)mn; m[1] = (uint8_t)(mn >> 8);
+        }
+        uint8_t *dst = fb + meta + 8ull * inf;   // the chunk's contiguous payload
+        copy_out16(s_pay, dst, total < kPayWords16 ? total : kPayWords16, tid);
+        if (total > kPayWords16) {   // (nearly) every tile of depth 16: the words the image had no room for
+            __syncthreads();
+            load_tile16(p.images + (size_t)k.f * p.frame_pixels, p.W, p.H, k.ty, k.tx, v);
+            pack_tile16(v, mn, d, s_pay, wbase + incl - d, kPayWords16);
+            __syncthreads();
+            copy_out16(s_pay, dst + 8ull * kPayWords16, total - kPayWords16, tid);
+        }
+        if (tid == 0) {
+            if (k.cf == 0u) {   // frame header and the first I32 fields (trap T1: elapsed travels as an F64; 0 here)
+                store_u32_bytes(fb, 2u);
+                store_u64_any(fb + 4, p.first_index + k.f);
+                store_u64_any(fb + 12, 0ull);
+                store_u32_bytes(fb + 20, p.T);
+                store_u32_bytes(fb + 24 + p.T, 2u * p.T);
+                if (p.frame_offsets) p.frame_offsets[k.f] = s_pre[1];
+            }
+            if (k.cf == p.chunks_per_frame - 1u) {   // the frame's word count is known here
+                const uint32_t words = inf + total;
+                store_u32_bytes(fb + 28 + 3ull * p.T, words);
+                if (p.frame_bytes) p.frame_bytes[k.f] = meta + 8ull * words;
+            }
+        }
+#ifdef DBDE_DIAG
+        if (tid == 0 && (c & 63u) == 5u) {   // a sample of workgroups, wave 0's view: ticket | load+reduce | pack | look-back | barrier wait | store
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint64_t t6 = wall_clock64();
+            for (int i = 0; i < 5; i++) atomicAdd(&p.diag[i], (unsigned long long)(dt[i + 1] - dt[i]));
+            atomicAdd(&p.diag[5], (unsigned long long)(t6 - dt[5]));
+            atomicAdd(&p.diag[6], 1ull);
+        }
+#endif
+        // the next chunk; the barrier also hands the LDS image back
+        if (!static_mode && tid == 0) s_chunk = atomicAdd(&p.ticket[0], 1u);
+        __syncthreads();
+        c = static_mode ? c + G : __builtin_amdgcn_readfirstlane(s_chunk);
+    }
 }
 
 // ---- decode ---------------------------------------------------------------------------------------------------
@@ -392,9 +450,15 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
 #endif
 }
 
-hipError_t launch_encode16(const Params16 &p, int n_frames, hipStream_t s) {
+int encode16_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc16_kernel, kChunkTiles16, 0) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+hipError_t launch_encode16(const Params16 &p, int n_frames, uint32_t resident_blocks, hipStream_t s) {
     const uint32_t n_chunks = (uint32_t)n_frames * p.chunks_per_frame;
-    hipLaunchKernelGGL(enc16_kernel, dim3(n_chunks), dim3(kChunkTiles16), 0, s, p);
+    hipLaunchKernelGGL(enc16_kernel, dim3(n_chunks < resident_blocks ? n_chunks : resident_blocks), dim3(kChunkTiles16), 0, s, p);
     return hipGetLastError();
 }
 

@@ -70,6 +70,8 @@ struct dbde_hip_ctx {
     // timing
     uint32_t exp_flags = 0;          // $DBDE_HIP_EXPERIMENT (tuning experiments only)
     uint32_t enc_grid = 0;           // resident workgroups for the persistent encoder
+    uint32_t enc16_grid = 0;         // the same for the DBDE16 encoder (queried at its first call)
+    int n_cu = 0;
     uint64_t *diag = nullptr;        // [16] phase cycle sums of diagnostic launches
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -178,6 +180,7 @@ int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out) {
         int per_cu = encode_blocks_per_cu();
         if (const char *g = getenv("DBDE_HIP_ENC_BLOCKS_PER_CU")) per_cu = atoi(g) > 0 ? atoi(g) : per_cu;
         ctx->enc_grid = (uint32_t)(per_cu * prop.multiProcessorCount);
+        ctx->n_cu = prop.multiProcessorCount;
     }
     if (const char *e = getenv("DBDE_HIP_EXPERIMENT")) ctx->exp_flags = (uint32_t)strtoul(e, nullptr, 0);
     void *p = nullptr;
@@ -582,7 +585,9 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     span_begin(ctx, 0);
     HIP_TRY(ctx, hipMemsetAsync(ctx->w16, 0, need, ctx->stream));
-    HIP_TRY(ctx, dbde16::launch_encode16(p, n_frames, ctx->stream));
+    if (!ctx->enc16_grid) ctx->enc16_grid = (uint32_t)(dbde16::encode16_blocks_per_cu() * ctx->n_cu);
+    p.force_tickets = (ctx->exp_flags & 1u) ? 1u : 0u;
+    HIP_TRY(ctx, dbde16::launch_encode16(p, n_frames, ctx->enc16_grid, ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;
 }

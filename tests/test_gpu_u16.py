@@ -81,6 +81,43 @@ def test_full_size_round_trip_and_spot_check(codec, o16):
     assert buf[32 + int(o[3]): 32 + int(o[3] + s[3])].cpu().numpy().tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("force_tickets", [False, True])
+@pytest.mark.parametrize("kind", ["mixed", "full"])
+def test_more_chunks_than_resident_workgroups(o16, kind, force_tickets):
+    """Launches whose chunks outnumber the resident workgroups: the persistent encoder claims chunk ids by static
+    strides once all workgroups have arrived, or by tickets (forced here through DBDE_HIP_EXPERIMENT bit 0);
+    `full` content (every tile of depth 16) also takes the path of chunks larger than the LDS payload image."""
+    import os
+    import torch
+    import dbde_video_cpp_amd as dv
+    if force_tickets:
+        os.environ["DBDE_HIP_EXPERIMENT"] = "1"
+    try:
+        c2 = dv.Codec(0)
+    finally:
+        os.environ.pop("DBDE_HIP_EXPERIMENT", None)
+    try:
+        W, H, n = 2048, 1536, 16    # 3072 chunks of 256 tiles
+        rng = np.random.default_rng(17 + len(kind))
+        imgs_h = make_images(rng, n, W, H, kind)
+        imgs = torch.from_numpy(imgs_h.view(np.int16)).cuda()
+        maxf = int(c2.L.dbde16_hip_max_frame_bytes(W, H))
+        for slot in (0, ((maxf + 255) // 256) * 256):
+            cap = (n - 1) * slot + maxf if slot else n * maxf
+            buf = torch.empty(32 + cap + 64, dtype=torch.uint8, device="cuda")
+            for rep in range(2):
+                offs, sizes = c2.encode_frames16(imgs, W, H, n, buf, 32, cap, slot_stride=slot)
+                back, res = c2.decode_frames16(buf, 32, cap, offs, W, H, n)
+                c2.sync()
+                assert torch.equal(back, imgs), (kind, force_tickets, slot, rep)
+            o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+            for f in (0, 7, 15):
+                want = pack16(o16, imgs_h[f], f)
+                assert buf[32 + int(o[f]): 32 + int(o[f] + s[f])].cpu().numpy().tobytes() == want.tobytes(), (kind, slot, f)
+    finally:
+        c2.close()
+
+
 def test_malformed_frames_are_rejected(codec, o16):
     import torch
     W, H = 24, 16

@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(hs, sizes, 8 * (size_t)B, hipMemcpyDeviceToHost));
     double packed = 0;
     for (int i = 0; i < B; i++) packed += (double)hs[i];
-    dbde_hip_timing_enable(c, 1);
+    if (!getenv("ABBENCH_NOTIMING")) dbde_hip_timing_enable(c, 1);   // (the event pairs cost a few us per call: off for latency runs)
     double ms[4] = {0, 0, 0, 0};
     uint64_t n[4] = {0, 0, 0, 0};
     dbde_hip_timing_read(c, ms, n, 1);

@@ -1234,7 +1234,12 @@ hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s) 
         hipLaunchKernelGGL(decode_index_split_kernel, dim3((uint32_t)n_frames * p.split), dim3(256), 0, s, p);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(decode_index_kernel, dim3(n_frames), dim3(1024), lds, s, p);
+    // one 16-byte piece of the depth array per thread and pass: small frames get small workgroups (1024 threads for a
+    // 256x256 frame -- 65 pieces -- made the index pass cost 70 % of the decode it serves)
+    const uint32_t pieces = (p.T + 15u) / 16u + 1u;
+    uint32_t threads = (pieces + 63u) / 64u * 64u;
+    threads = threads < 64u ? 64u : (threads > 1024u ? 1024u : threads);
+    hipLaunchKernelGGL(decode_index_kernel, dim3(n_frames), dim3(threads), lds, s, p);
     return hipGetLastError();
 }
 

@@ -56,4 +56,47 @@ for r in range(a.rounds):
     frames_done += 3 * n
     del imgs, buf, back, res
     print(f"round {r:3d}: {W}x{H} n={n:5d} {content:7s} {'concat' if concat else 'slots '} ok", flush=True)
-print(f"soak ok: {a.rounds} rounds, {frames_done} frame round trips, {time.time() - t0:.0f} s")
+# DBDE16 (extension): the persistent encoder's static / ticket chunk ids and the record sums, against itself
+# (round trip) and, for one frame per round, against the DBDE16 oracle's bytes
+import ctypes as C  # noqa: E402
+from oracle_ffi import ORACLE_SO  # noqa: E402
+from test_oracle_u16 import pack16, u8p, u16p  # noqa: E402
+o16 = C.CDLL(ORACLE_SO)
+o16.dbde16_oracle_max_frame_bytes.restype = C.c_size_t
+o16.dbde16_oracle_max_frame_bytes.argtypes = [C.c_int, C.c_int]
+o16.dbde16_oracle_pack_frame.restype = C.c_size_t
+o16.dbde16_oracle_pack_frame.argtypes = [C.c_uint64, u16p, C.c_int, C.c_int, u8p]
+u16_rounds = max(a.rounds // 4, 1)
+for r in range(u16_rounds):
+    W, H = [(2048, 1536), (1921, 1081), (4096, 3072), (640, 480)][int(rng.integers(0, 4))]
+    n = int(rng.choice([1, 3, 16, 40]))
+    kind = str(rng.choice(["full", "mixed", "small"]))
+    d = rng.integers(0, 17, size=(n, (H + 7) // 8, (W + 7) // 8))
+    dd = np.repeat(np.repeat(d, 8, axis=1), 8, axis=2)[:, :H, :W]
+    noise = rng.integers(0, 65536, size=(n, H, W))
+    if kind == "full":
+        img = noise
+    elif kind == "mixed":
+        img = np.minimum(20000, 65535 - ((1 << dd) - 1)) + (noise & ((1 << dd) - 1))
+    else:
+        img = noise >> 11
+    imgs_h = np.ascontiguousarray(img.astype(np.uint16))
+    imgs = torch.from_numpy(imgs_h.view(np.int16)).cuda()
+    maxf = int(codec.L.dbde16_hip_max_frame_bytes(W, H))
+    concat = bool(rng.integers(0, 2))
+    slot = 0 if concat else ((maxf + 255) // 256) * 256
+    cap = n * maxf if concat else (n - 1) * slot + maxf
+    buf = torch.empty(32 + cap + 64, dtype=torch.uint8, device="cuda")
+    for rep in range(3):
+        offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap, slot_stride=slot)
+        back, res = codec.decode_frames16(buf, 32, cap, offs, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs), ("u16", r, rep, W, H, n, kind, concat)
+    o, sz = offs.cpu().numpy(), sizes.cpu().numpy()
+    f = n // 2
+    want = pack16(o16, imgs_h[f], f)
+    assert buf[32 + int(o[f]): 32 + int(o[f] + sz[f])].cpu().numpy().tobytes() == want.tobytes(), ("u16", r, W, H, n, kind)
+    frames_done += 3 * n
+    del imgs, buf, back
+    print(f"u16 round {r:3d}: {W}x{H} n={n:3d} {kind:6s} {'concat' if concat else 'slots '} ok", flush=True)
+print(f"soak ok: {a.rounds} rounds (+{u16_rounds} DBDE16), {frames_done} frame round trips, {time.time() - t0:.0f} s")

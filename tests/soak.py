@@ -3,7 +3,7 @@
 and spot-checked against the oracle's bytes.  Looks for rare, timing-dependent corruption in the
 persistent encoder (hand-placed waits, cross-workgroup hand-off), which short parity tests could miss.
 
-    python profiles/soak.py [--rounds 40] [--seed 1]
+    python tests/soak.py [--rounds 40] [--seed 1]   (test infrastructure: the oracle is its checker; log: profiles/soak_r02.log)
 """
 import argparse
 import os

@@ -105,3 +105,29 @@ def test_no_scratch_and_expected_occupancy(listing):
     assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, enc
     dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi")]
     assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 96 and d["lds"] <= 40 * 1024 for d in dec), dec
+
+
+def test_decoder_uses_sdwa_field_expansion(listing):
+    """The decoder's field expansion is three SDWA shifts per four pixels: 96 in the general unpack of
+    each instance (two tiles x eight rows x six); a rewrite that silently falls back to mask / bfe / shift-or chains
+    shows here."""
+    body = "\n".join(function_body(listing, "_ZN4dbde13decode_kernelILi0ELb0EEEvNS_9DecParamsE"))
+    assert body.count("v_lshrrev_b32_sdwa") >= 96, body.count("v_lshrrev_b32_sdwa")
+
+
+def test_dbde16_kernels_do_not_spill():
+    """DBDE16: the encoder is built for four waves per SIMD (LDS allows four workgroups per CU) and must not spill; the
+    decoder stays LDS-bound."""
+    r = subprocess.run(["make", "-s", "-C", CSRC, "asm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(os.path.join(CSRC, "dbde16_kernels.s")).read()
+    md = text[text.index("amdhsa.kernels:"):]
+    seen = {}
+    for entry in re.split(r"\n  - \.", md)[1:]:
+        get = lambda k: re.search(r"\.?%s:\s+(\S+)" % k, entry).group(1)
+        seen[get("name")] = (int(get("vgpr_count")), int(get("private_segment_fixed_size")), int(get("group_segment_fixed_size")))
+    enc = [v for k, v in seen.items() if "enc16_kernel" in k]
+    dec = [v for k, v in seen.items() if "dec16_kernel" in k]
+    assert enc and dec
+    assert all(v[0] <= 128 and v[1] == 0 and v[2] <= 40 * 1024 for v in enc), enc
+    assert all(v[0] <= 96 and v[1] == 0 and v[2] <= 40 * 1024 for v in dec), dec

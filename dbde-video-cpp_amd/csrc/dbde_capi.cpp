@@ -294,7 +294,10 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     // small launches (one frame per call above all): one workgroup per chunk, self-cleaning workspace, no memset
     const bool small = n_chunks < ctx->enc_grid;
     span_begin(ctx, 0);
-    if (!small || !ctx->lb_clean) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
+    // A large launch clears what it is about to use; the whole block (the high-water mark of every launch so far) is
+    // cleared only when a small launch finds it dirty.  Small launches leave what they used clean.
+    if (!small) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
+    else if (!ctx->lb_clean) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
     ctx->lb_clean = small;
 
     EncParams p;
@@ -451,6 +454,7 @@ int dbde_hip_index_stream_async(dbde_hip_ctx *ctx, const uint8_t *d_stream, size
         sp.gran = g.T % 4 == 0 ? 8u : (g.T % 2 == 0 ? 4u : 2u);   // frame lengths 32 + 2T + 8 n64 are multiples of this
         sp.seg_bytes = (stream_bytes + n_seg - 1) / n_seg;
         sp.seg_cap = (uint32_t)(sp.seg_bytes / meta + 3);
+        if (sp.seg_cap > (uint32_t)max_frames + 3u) sp.seg_cap = (uint32_t)max_frames + 3u;   // no list needs more than the caller takes (tiny frames: T = 1, meta = 34)
         // workspace: [found 8 x 64][arrive 4 x 64] (kept zero by the kernel) | lists | start, end, count, ended
         const size_t fixed = 64 * 8 + 64 * 4, lists = (size_t)n_seg * sp.seg_cap * 8, need = fixed + lists + n_seg * 32 + 64;
         const size_t had = ctx->scan_ws_bytes;
@@ -490,18 +494,21 @@ int dbde_hip_scan_ahead(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t strea
     // the walk may read what the main stream has produced so far (and the cursor a previous walk left)
     HIP_TRY(ctx, hipEventRecord(ctx->scan_ev_main, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->scan_stream, ctx->scan_ev_main, 0));
-    if (ctx->timing) {
-        TimedSpan sp;
-        sp.kind = 3;
-        if (hipEventCreate(&sp.a) == hipSuccess && hipEventCreate(&sp.b) == hipSuccess) {
-            (void)hipEventRecord(sp.a, ctx->scan_stream);
-            HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, d_cursor, ctx->scan_stream));
-            (void)hipEventRecord(sp.b, ctx->scan_stream);
-            ctx->spans.push_back(sp);
-        }
-    } else {
-        HIP_TRY(ctx, launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, d_cursor, ctx->scan_stream));
+    // the walk is launched whether or not its timing bracket could be created (as span_begin / span_end)
+    TimedSpan sp;
+    sp.kind = 3;
+    bool timed = false;
+    if (ctx->timing && hipEventCreate(&sp.a) == hipSuccess) {
+        if (hipEventCreate(&sp.b) == hipSuccess) timed = true;
+        else (void)hipEventDestroy(sp.a);
     }
+    if (timed) (void)hipEventRecord(sp.a, ctx->scan_stream);
+    const hipError_t e_walk = launch_scan_stream(d_stream, stream_bytes, g.T, max_frames, d_frame_offsets, d_n_found, d_cursor, ctx->scan_stream);
+    if (timed) {
+        (void)hipEventRecord(sp.b, ctx->scan_stream);
+        ctx->spans.push_back(sp);
+    }
+    HIP_TRY(ctx, e_walk);
     HIP_TRY(ctx, hipEventRecord(ctx->scan_ev_done, ctx->scan_stream));
     return DBDE_HIP_OK;
 }

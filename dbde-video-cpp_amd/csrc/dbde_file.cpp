@@ -36,6 +36,14 @@ bool refill(dbde_file_walker *w) {
 
 }  // namespace
 
+// Exported by the reference's object file although dbde_util.h does not declare it (dbde_util.cpp:394-406): makes sure
+// a worst-case frame's worth of bytes lies past the read position, sliding the unread bytes to the front and topping the
+// window up from the file.  False only on a read error.  Kept so that the two libraries export the same symbol set.
+bool dbde_advance_file_buffer(dbde_file_walker &w) {
+    if (!w.fptr || !w.buffer) return false;
+    return refill(&w);
+}
+
 dbde_file_walker dbde_start_file_walk(const char *name, int frames_buffered, video_header *vh) {
     dbde_file_walker w;
     memset(&w, 0, sizeof w);

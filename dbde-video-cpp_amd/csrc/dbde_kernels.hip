@@ -124,6 +124,12 @@ __device__ __forceinline__ uint64_t f64_to_u64_x86(double v) {
     return high ? (r ^ 0x8000000000000000ull) : r;
 }
 
+// Does [off, off + len) lie inside [0, extent)?  Written so that it cannot wrap: `off` may be anything a caller left
+// in an offsets array or a cursor (a stale -1, 2^63, ...), and `off + len <= extent` would accept offsets near 2^64.
+__device__ __forceinline__ bool in_extent(uint64_t off, uint64_t len, uint64_t extent) {
+    return off <= extent && len <= extent - off;
+}
+
 // ---------------------------------------------------------------------------------------
 // ENCODE
 // ---------------------------------------------------------------------------------------
@@ -697,12 +703,12 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
                 }
             }
         };
-        // Order.  The chunk's AGG record must not wait for anything: the scanner's answer to it (its INC
-        // record) is what the workgroup needs one step from now, and the scanner takes 3-5 us to give it.
-        // Round 1 polled the mailbox FIRST, in wave 0: that wave, always the last to finish its statistics,
-        // delayed the AGG of cur by its wait for the INC of prev -- a latency loop that cost 40-60 % of every
-        // workgroup's time (profiles/r02e diag).  Now wave 0 reduces cur first, polls, and only then issues its
-        // prefetch (consumed at the top of its next step); the other waves prefetch first as before.
+        // Order (DBDE_POLL, A/B builds).  The shipped order is 0: lane 0 polls prev's mailbox FIRST -- prev's AGG was
+        // published a whole step ago, so the scanner has normally answered -- then every wave issues its prefetch and
+        // reduces cur.  Vector-memory results return in issue order, so a poll issued behind the prefetch would wait
+        // for the pixels.  The alternatives (1: poll after the statistics; 2: wave 0 reduces cur first, polls, and only
+        // then prefetches) measured equal or worse in round 2 (the prefetch then arrives late); the wait
+        // that remains is the in-order prefix itself, not the position of the poll.
 #if DBDE_POLL == 0
         mailbox();
         load_chunk<IN_MODE>(p, nxt, na, nb);
@@ -966,7 +972,7 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
     const uint64_t off = p.frame_offsets[f];
     const uint64_t meta_t = (1ull + p.min_bytes) * T;   // bytes of the depth and minimum arrays
     const uint64_t need = 32ull + meta_t;   // header + metadata must lie inside the stream
-    const bool in_range = off + need <= p.stream_bytes;
+    const bool in_range = in_extent(off, need, p.stream_bytes);
     const uint8_t *fb = p.stream + off;
 
     for (uint32_t k = tid; k < cpf; k += blockDim.x) s_sum[k] = 0;
@@ -1083,7 +1089,7 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
         bool ok = in_range;
         uint32_t field = 0;
         uint64_t index = 0, elapsed = 0, consumed = 20;
-        if (off + 20 <= p.stream_bytes) {
+        if (in_extent(off, 20, p.stream_bytes)) {
             field = load_u32_bytes(fb);
             index = load_u64_bytes(fb + 4);
             elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
@@ -1094,7 +1100,7 @@ __global__ __launch_bounds__(1024) void decode_index_kernel(IdxParams p) {
             const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + meta_t);
             ok = nb == (int32_t)T && nm == (int32_t)(T * p.min_bytes) && n64 == (int32_t)total && !(s_flags & 1u);
             // the payload itself must also be inside the stream
-            if (ok && off + need + 8ull * total > p.stream_bytes) ok = false;
+            if (ok && !in_extent(off, need + 8ull * total, p.stream_bytes)) ok = false;
             if (ok) consumed = need + 8ull * total;
         }
         p.frame_ok[f] = ok ? 1u : 0u;
@@ -1127,7 +1133,7 @@ __global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
     const uint64_t off = p.frame_offsets[f];
     const uint64_t meta_t = (1ull + p.min_bytes) * T;
     const uint64_t need = 32ull + meta_t;
-    const bool in_range = off + need <= p.stream_bytes;
+    const bool in_range = in_extent(off, need, p.stream_bytes);
     const uint8_t *fb = p.stream + off;
     uint32_t *co = p.chunk_off + (size_t)f * (cpf + 1u);
 
@@ -1198,7 +1204,7 @@ __global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
         bool ok = in_range;
         uint32_t field = 0;
         uint64_t index = 0, elapsed = 0, consumed = 20;
-        if (off + 20 <= p.stream_bytes) {
+        if (in_extent(off, 20, p.stream_bytes)) {
             field = load_u32_bytes(fb);
             index = load_u64_bytes(fb + 4);
             elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
@@ -1208,7 +1214,7 @@ __global__ __launch_bounds__(256) void decode_index_split_kernel(IdxParams p) {
             const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
             const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + meta_t);
             ok = nb == (int32_t)T && nm == (int32_t)(T * p.min_bytes) && n64 == (int32_t)total && !(flags & 1u);
-            if (ok && off + need + 8ull * total > p.stream_bytes) ok = false;
+            if (ok && !in_extent(off, need + 8ull * total, p.stream_bytes)) ok = false;
             if (ok) consumed = need + 8ull * total;
         }
         p.frame_ok[f] = ok ? 1u : 0u;
@@ -1464,7 +1470,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     if (SELF_INDEX) {
         const uint32_t T = p.T;
         const uint64_t need = 32ull + 2ull * T;
-        const bool in_range = foff + need <= p.stream_bytes;
+        const bool in_range = in_extent(foff, need, p.stream_bytes);
         uint32_t s_before = 0, s_mine = 0, s_all = 0, bad = 0;
         if (in_range) {
             // 16-byte aligned pieces of the depth array (bytes outside [0, T) masked off), four in flight per thread
@@ -1523,12 +1529,12 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
             const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
             const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
             okf = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && !flag;
-            if (okf && foff + need + 8ull * total > p.stream_bytes) okf = false;   // the payload must lie inside the stream too
+            if (okf && !in_extent(foff, need + 8ull * total, p.stream_bytes)) okf = false;   // the payload must lie inside the stream too
         }
         if (cf == 0u && tid == 0 && p.results) {   // the frame's result record: dbde_unpack_frame's return value
             uint32_t field = 0;
             uint64_t index = 0, elapsed = 0;
-            if (foff + 20 <= p.stream_bytes) {
+            if (in_extent(foff, 20, p.stream_bytes)) {
                 field = load_u32_bytes(fb);
                 index = load_u64_bytes(fb + 4);
                 elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
@@ -1834,26 +1840,41 @@ hipError_t launch_decode(const DecParams &p, int img_mode, bool self_index, hipS
 // ---------------------------------------------------------------------------------------
 // stream scanner: frame-to-frame hop (reference README.md:12-23: sizes are only in-band)
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld_u32_any(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// One exact hop: the frame at `off` (length in *len) if its fixed part and its payload lie inside the stream.
+__device__ __forceinline__ bool frame_at(const uint8_t *stream, uint64_t stream_bytes, uint64_t meta, uint32_t T, uint64_t off, uint64_t *len) {
+    if (!in_extent(off, meta, stream_bytes)) return false;
+    const uint32_t n64 = ld_u32_any(stream + off + 28 + 2ull * T);
+    *len = meta + 8ull * n64;
+    return (int32_t)n64 >= 0 && in_extent(off, *len, stream_bytes);
+}
+
 // One lane walks the chain (each hop needs the previous frame's word count: a dependent read of HBM, about a
 // microsecond); `cursor`, when given, is where the walk starts and where it is left, so a stream can be walked
 // a batch at a time while the previous batch is being decoded (dbde_hip_scan_ahead).
 __global__ void scan_stream_kernel(const uint8_t *stream, uint64_t stream_bytes, uint32_t T, int max_frames,
                                    uint64_t *offsets, uint32_t *count, uint64_t *cursor) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    __builtin_amdgcn_s_setprio(3);
-    uint64_t off = cursor ? *cursor : 0ull;
-    int n = 0;
-    const uint64_t meta = 32ull + 2ull * T;
-    while (n < max_frames && off + meta <= stream_bytes) {
-        uint32_t n64;
-        __builtin_memcpy(&n64, stream + off + 28 + 2ull * T, 4);   // any alignment: one dword load
-        const uint64_t len = meta + 8ull * n64;
-        if ((int32_t)n64 < 0 || off + len > stream_bytes) break;
-        offsets[n++] = off;
-        off += len;
+    __shared__ int s_n;
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        uint64_t off = cursor ? *cursor : 0ull;
+        int n = 0;
+        const uint64_t meta = 32ull + 2ull * T;
+        uint64_t len;
+        while (n < max_frames && frame_at(stream, stream_bytes, meta, T, off, &len)) {
+            offsets[n++] = off;
+            off += len;
+        }
+        *count = (uint32_t)n;
+        if (cursor) *cursor = off;
+        s_n = n;
     }
-    *count = (uint32_t)n;
-    if (cursor) *cursor = off;
+    __syncthreads();
+    // entries past the count: an offset no frame can have (every extent check rejects it, see in_extent), so a decode
+    // bounded by max_frames instead of the count reports those frames as failed rather than decoding stale offsets
+    for (int i = s_n + (int)threadIdx.x; i < max_frames; i += (int)blockDim.x) offsets[i] = ~0ull;
 }
 
 hipError_t launch_scan_stream(const uint8_t *stream, uint64_t stream_bytes, uint32_t T, int max_frames,
@@ -1877,16 +1898,6 @@ hipError_t launch_scan_stream(const uint8_t *stream, uint64_t stream_bytes, uint
 // walk's); a segment that was fooled by payload bytes is simply never arrived at, and the exact walk goes on hop by
 // hop until it meets the next segment start that it does arrive at.  Exact by construction, K-fold shorter in the
 // usual case.
-__device__ __forceinline__ uint32_t ld_u32_any(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-
-// One exact hop: the frame at `off` (length in *len) if its fixed part and its payload lie inside the stream.
-__device__ __forceinline__ bool frame_at(const uint8_t *stream, uint64_t stream_bytes, uint64_t meta, uint32_t T, uint64_t off, uint64_t *len) {
-    if (off + meta > stream_bytes) return false;
-    const uint32_t n64 = ld_u32_any(stream + off + 28 + 2ull * T);
-    *len = meta + 8ull * n64;
-    return (int32_t)n64 >= 0 && off + *len <= stream_bytes;
-}
-
 __global__ __launch_bounds__(1024) void scan_spec_kernel(ScanParams p) {
     __shared__ uint32_t s_last;
     const uint32_t M = p.wg_per_seg, j = blockIdx.x / M, m = blockIdx.x - j * M, tid = threadIdx.x;
@@ -1908,7 +1919,7 @@ __global__ __launch_bounds__(1024) void scan_spec_kernel(ScanParams p) {
 #pragma unroll
             for (uint32_t k = 0; k < 16u; k++) {
                 const uint64_t c = base + ((uint64_t)k * 1024u + tid) * p.gran;
-                w[k] = c + meta <= p.stream_bytes ? ld_u32_any(p.stream + c) : 0u;
+                w[k] = in_extent(c, meta, p.stream_bytes) ? ld_u32_any(p.stream + c) : 0u;
             }
 #pragma unroll
             for (uint32_t k = 0; k < 16u; k++) {
@@ -1992,6 +2003,7 @@ __global__ __launch_bounds__(1024) void scan_stitch_kernel(ScanParams p, uint32_
         for (uint32_t i = tid & 63u; i < s_count[j]; i += 64u)
             if (s_base[j] + i < total) offsets[s_base[j] + i] = pos[i];
     }
+    for (uint32_t i = total + tid; i < (uint32_t)max_frames; i += 1024u) offsets[i] = ~0ull;   // as scan_stream_kernel
 }
 
 hipError_t launch_scan_spec(const ScanParams &p, uint32_t n_seg, int max_frames, uint64_t *d_offsets, uint32_t *d_count, hipStream_t s) {

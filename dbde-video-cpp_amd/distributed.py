@@ -34,7 +34,7 @@ def gather_stream_begin(segment, nbytes, dst=0, group=None, out=None, max_messag
     without waiting for the bytes: (stream_view_or_None, sizes, works).  The size exchange (a few bytes,
     all_gather) is synchronous -- both ends need the sizes to post matching pieces -- the payload is not:
     call gather_stream_end(works) before `segment` is overwritten or `out` is read.  This is what lets the
-    gather of batch k run beside the encode of batch k+1 (StreamEncoder below)."""
+    gather of batch k run beside the encode of batch k+1 (streaming.RoundTripStream)."""
     piece = int(max_message_bytes or MAX_MESSAGE_BYTES)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

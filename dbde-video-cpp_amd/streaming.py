@@ -44,8 +44,8 @@ class RoundTripStream:
         self.inp = [torch.empty((batch, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.out = [codec.alloc_stream(W, H, batch) for _ in range(2)]            # (buf, lead, cap)
         self.img = torch.empty((batch, H, W), dtype=torch.uint8, device=dev) if decode else None
-        self.offs = [torch.empty(batch, dtype=torch.int64, device=dev) for _ in range(2)]
-        self.sizes = [torch.empty(batch, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.offs = [torch.zeros(batch, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.sizes = [torch.zeros(batch, dtype=torch.int64, device=dev) for _ in range(2)]
         self.res = torch.empty((batch, 4), dtype=torch.int64, device=dev)
         self.total_pinned = torch.empty(2, dtype=torch.int64).pin_memory()
         self.ev_src = [torch.cuda.Event() for _ in range(2)]
@@ -126,8 +126,9 @@ class RoundTripStream:
                 a, b = self._post_gather((k - 1) % 2, count(k - 1), world, rank)
                 packed, gathered = packed + a, gathered + b
         if self.gather:
-            a, b = self._post_gather((nb - 1) % 2, count(nb - 1), world, rank)
-            packed, gathered = packed + a, gathered + b
+            if nb:     # (a rank whose block is empty -- fewer frames than ranks -- only posts the empty rounds below)
+                a, b = self._post_gather((nb - 1) % 2, count(nb - 1), world, rank)
+                packed, gathered = packed + a, gathered + b
             for _ in range(nb, rounds or nb):          # blocks differ by a frame: keep the collective calls in step
                 a, b = self._post_gather((nb - 1) % 2, 0, world, rank)
                 gathered += b

@@ -124,7 +124,9 @@ int dbde_hip_index_stream(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t str
 /* The same walk, enqueued on the context's stream without waiting for it: the frame count lands in the
  * DEVICE word *d_n_found.  A dbde_hip_decode_frames call enqueued behind it may use d_frame_offsets
  * directly (a reader that knows how many frames it expects, or that bounds the decode by max_frames and
- * inspects the per-frame results: entries past the count are left untouched). */
+ * inspects the per-frame results: entries past the count are set to 0xFFFFFFFFFFFFFFFF, an offset every
+ * extent check rejects -- those frames report header.u64s = 0xFFFFFFFF, consumed = 20, index = elapsed_ns = 0
+ * and leave their image untouched; the same holds for any offset outside [0, stream_bytes), however large). */
 int dbde_hip_index_stream_async(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes, int W,
                                 int H, int max_frames, uint64_t *d_frame_offsets, uint32_t *d_n_found);
 

@@ -80,5 +80,8 @@ struct dbde_file_walker {
 dbde_file_walker dbde_start_file_walk(const char *name, int frames_buffered, video_header *vh);
 bool dbde_walk_a_file(dbde_file_walker *walker, frame_header *fh, uint8_t *image);
 void dbde_end_file_walk(dbde_file_walker *walker);
+/* Not declared by the reference's header but exported by its object file (dbde_util.cpp:394): refills the walker's
+ * byte window; false on a read error. */
+bool dbde_advance_file_buffer(dbde_file_walker &w);
 
 #endif

@@ -15,7 +15,7 @@ REFERENCE_MANGLED = [
     "_Z23dbde_unpack_8x8_partialhhPhmiiS_", "_Z17dbde_unpack_imagePhiiS_",
     "_Z24dbde_unpack_frame_headerPPh", "_Z17dbde_unpack_framePPhiiS_", "_Z24dbde_unpack_video_headerPPh",
     "_Z20dbde_start_file_walkPKciP12video_header", "_Z16dbde_walk_a_fileP16dbde_file_walkerP12frame_headerPh",
-    "_Z18dbde_end_file_walkP16dbde_file_walker",
+    "_Z18dbde_end_file_walkP16dbde_file_walker", "_Z24dbde_advance_file_bufferR16dbde_file_walker",
 ]
 
 

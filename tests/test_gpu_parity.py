@@ -239,7 +239,7 @@ def test_index_stream(codec):
 
 
 def test_index_stream_speculative_walk(codec, oracle):
-    """Long streams are walked in up to 64 segments at once, each from a position that LOOKS like a frame start, and
+    """Long streams are walked in up to 16 segments at once, each from a position that LOOKS like a frame start, and
     stitched only where the exact chain arrives (scan_spec_kernel).  Offsets must equal the encoder's for honest
     streams, for tiny frames (many per segment), for frames larger than a segment, for a truncated tail, for a
     max_frames cut -- and for a stream salted with byte patterns that look exactly like frame starts."""
@@ -308,6 +308,58 @@ def test_scan_ahead_reader_pipeline(codec):
         assert torch.equal(found[:want], offs[:want]) and (found[want:] == -1).all()
         assert torch.equal(out[:want], imgs[:want]) and (out[want:] == 0xEE).all()
         assert int(cursor.item()) == int((offs[want - 1] + sizes[want - 1]).item())
+
+
+@pytest.mark.parametrize("W,H,n", [(64, 64, 4), (1024, 768, 3), (640, 480, 300)])
+def test_wild_frame_offsets_are_rejected(codec, W, H, n):
+    """Offsets are the caller's (a stale -1 from a reused array, a cursor gone wrong): any offset outside
+    [0, stream_bytes) must be rejected by every index form -- self-indexing decode (64x64), the split index kernel
+    (1024x768 x 3) and one index workgroup per frame (640x480 x 300) -- with no wrap-around in `off + need`: the
+    frame reports u64s = 0xFFFFFFFF, consumed = 20, index = elapsed = 0 (nothing was read), its image is untouched,
+    and the frames around it decode as usual.  The stream is its own allocation (it starts at byte 0 of a block)."""
+    import torch
+    imgs = codec.synth_frames("mixed", SEED, 9, n, W, H)
+    frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=9)
+    total = int((offs[-1] + sizes[-1]).item())
+    stream = buf[lead:lead + total].clone()
+    need = 32 + 2 * ((W + 7) // 8) * ((H + 7) // 8)
+    wild = [-1, -need, -need - 8, -(1 << 63), (1 << 63) - 1, total, total - 10, -total, -(total - 20)]
+    for i, v in enumerate(wild):
+        bad = sorted({i % n, n - 1})
+        o = offs.clone()
+        for k in bad:
+            o[k] = v
+        canvas = torch.full_like(imgs, 0xEE)
+        back, res = codec.decode_frames(stream, 0, total, o, W, H, n, images=canvas)
+        codec.sync()
+        rr = codec.parse_results(res)
+        for f in range(n):
+            if f in bad:
+                assert rr[f] == (0xFFFFFFFF, 0, 0, 20), (v, f, rr[f])
+                assert (back[f] == 0xEE).all(), (v, f)
+            else:
+                assert rr[f] == (2, 9 + f, 0, len(frames[f])), (v, f, rr[f])
+                assert torch.equal(back[f], imgs[f]), (v, f)
+
+
+def test_scanners_mark_unvisited_offsets(codec):
+    """dbde_hip.h: entries of the offsets array past the frame count are set to 2^64 - 1 by both walkers (serial and
+    speculative), so a decode bounded by max_frames reports them as failed instead of decoding stale offsets."""
+    import torch
+    for W, H, n in ((200, 123, 7), (512, 512, 40)):       # short stream: serial hop; long one: speculative segments
+        imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n)
+        total = int((offs[-1] + sizes[-1]).item())
+        found = torch.arange(n + 9, dtype=torch.int64, device=imgs.device) * 8      # stale but plausible entries
+        count = torch.zeros(1, dtype=torch.int32, device=imgs.device)
+        codec.index_stream_async(buf, lead, total, W, H, n + 9, found, count)
+        canvas = torch.full((n + 9, H, W), 0xEE, dtype=torch.uint8, device=imgs.device)
+        back, res = codec.decode_frames(buf, lead, total, found, W, H, n + 9, images=canvas)
+        codec.sync()
+        assert int(count.item()) == n and torch.equal(found[:n], offs) and (found[n:] == -1).all()
+        rr = codec.parse_results(res)
+        assert all(r == (0xFFFFFFFF, 0, 0, 20) for r in rr[n:]) and (back[n:] == 0xEE).all()
+        assert torch.equal(back[:n], imgs)
 
 
 @pytest.mark.parametrize("W,H,n,mode", [(200, 123, 3, "mixed"), (8, 8, 1, "noise8"), (9, 9, 2, "mixed"),

@@ -102,38 +102,90 @@ def progress(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(make_frames, W, H, budget_s=12.0):
+def cpu_baseline(make_frames, W, H, budget_s=8.0):
     """Reference (oracle/_ref, kind 'reference') or oracle port on ALL the host cores this job may use: every
-    thread round-trips its own frame until `budget_s` seconds of wall time have passed."""
+    thread round-trips its own frame until the budget has passed (the reference's own timing loop brackets
+    dbde_pack_frame / dbde_unpack_frame the same way, dbde_util_test.cpp:326-349).  `make_frames(content, n)` ->
+    host frames.  noise8 (all depth 8: the reference's SIMD fast path) is `value`; `mixed` (depths 0..8: its scalar
+    bit loops, dbde_util.cpp:87-100,234-242) is reported beside it.  Single-thread figures are HOT: one untimed
+    round trip (first-touch page faults, caches), then the mean of >= 5."""
     from oracle_ffi import Oracle, Reference
     impl, kind = (Reference(), "reference") if Reference.available() else (Oracle(), "port")
     cores, visible = host_cores()
     n_distinct = min(cores, 32)
-    images_host = make_frames(n_distinct)
-    t1 = impl.time_roundtrip(images_host[0:1], 1, W, H, 1)[0]   # calibrate on one frame, one thread
-    chunk = max(1, int(0.5 / max(t1, 1e-4)))                    # round trips per call (about half a second)
-    done = [0] * cores
-    bad = [0] * cores
-    deadline = time.time() + budget_s
 
-    def work(k):
-        j = k % n_distinct
-        while time.time() < deadline:
-            r = impl.time_roundtrip(images_host[j:j + 1], 1, W, H, chunk)
-            done[k] += chunk
-            bad[k] += r[3]
+    def leg(content, budget):
+        images_host = make_frames(content, n_distinct)
+        impl.time_roundtrip(images_host[0:1], 1, W, H, 1)                 # warm-up, untimed
+        reps = 5
+        t1 = impl.time_roundtrip(images_host[0:1], 1, W, H, reps)[0] / reps
+        chunk = max(1, int(0.5 / max(t1, 1e-4)))                         # round trips per call (about half a second)
+        done, bad = [0] * cores, [0] * cores
+        deadline = time.time() + budget
 
-    t0 = time.time()
-    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    wall = time.time() - t0
-    frames = sum(done)
-    return {"value": round(frames / wall, 2), "unit": "frames/s", "cores": cores, "kind": kind,
-            "host_cores_visible": visible,
+        def work(k):
+            j = k % n_distinct
+            while time.time() < deadline:
+                r = impl.time_roundtrip(images_host[j:j + 1], 1, W, H, chunk)
+                done[k] += chunk
+                bad[k] += r[3]
+
+        t0 = time.time()
+        th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        wall = time.time() - t0
+        return {"value": round(sum(done) / wall, 2), "single_thread_frames_per_s": round(1.0 / t1, 2),
+                "single_thread_reps": reps, "round_trips": sum(done), "seconds": round(wall, 1),
+                "mismatched_pixels": int(sum(bad))}
+
+    n8 = leg("noise8", budget_s)
+    mx = leg("mixed", budget_s * 0.75)
+    return {"value": n8["value"], "unit": "frames/s", "cores": cores, "kind": kind, "host_cores_visible": visible,
             "sample": f"{cores} threads (every core this job may use; {visible} visible) round-tripping one "
-                      f"{W}x{H} noise8 frame each for {wall:.1f} s ({frames} round trips)",
-            "single_thread_frames_per_s": round(1.0 / t1, 2), "mismatched_pixels": int(sum(bad))}
+                      f"{W}x{H} noise8 frame each for {n8['seconds']} s ({n8['round_trips']} round trips); "
+                      f"single thread: mean of {n8['single_thread_reps']} round trips after one untimed",
+            "single_thread_frames_per_s": n8["single_thread_frames_per_s"], "mismatched_pixels": n8["mismatched_pixels"],
+            "mixed": {"value": mx["value"], "single_thread_frames_per_s": mx["single_thread_frames_per_s"],
+                      "seconds": mx["seconds"], "round_trips": mx["round_trips"], "mismatched_pixels": mx["mismatched_pixels"],
+                      "note": "depths 0..8 uniform: the reference's scalar bit-packing path"}}
+
+
+def golden_sha(W, H, content):
+    """{frame: (sha256, bytes)} of the reference's own packed frames for this shape / content, from the committed
+    fixture (tests/golden/manifest.json "big": made by tests/golden/make_golden.py with the real reference).  Data,
+    not code: no oracle is imported here."""
+    try:
+        m = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
+    except Exception:
+        return {}
+    return {e["frame"]: (e["packed_sha"], e["packed_bytes"]) for e in m.get("big", [])
+            if e["W"] == W and e["H"] == H and e["mode"] == content}
+
+
+class Watchdog:
+    """The exchange legs are the one part of a multi-rank run that can hang (a collective nobody answers).  If the
+    block does not finish in `seconds`, `on_timeout()` runs (rank 0 prints the line it has) and the process leaves."""
+
+    def __init__(self, seconds, on_timeout):
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.on_timeout = on_timeout
+
+    def _fire(self):
+        try:
+            self.on_timeout()
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
 
 
 class Bench:
@@ -189,8 +241,20 @@ class Bench:
         for _ in range(warmup):
             step()
         codec.sync()
+        sha_ok = None
         if check:   # parity gate on the measured configuration
             assert torch.equal(out, imgs), f"round trip mismatch ({W}x{H} {content} {layout})"
+            # ... and not on round-trip identity alone (an encoder / decoder pair wrong in the same way would pass it):
+            # the packed bytes of frames 0 and 3 against the SHA-256 of the REFERENCE's output for the same frames
+            want = golden_sha(W, H, content) if rank == 0 else {}
+            if want:
+                o_h, s_h = offs.cpu().numpy(), sizes.cpu().numpy()
+                sha_ok = True
+                for f, (sha, nbytes) in want.items():
+                    if f < B:
+                        got = buf[lead + int(o_h[f]):lead + int(o_h[f]) + int(s_h[f])].cpu().numpy().tobytes()
+                        sha_ok = sha_ok and len(got) == nbytes and hashlib.sha256(got).hexdigest() == sha
+                assert sha_ok, f"packed frames differ from the reference's ({W}x{H} {content})"
             if scan:
                 assert torch.equal(found, offs), "stream scanner offsets differ from the encoder's"
                 assert int(count.item()) == B, "stream scanner lost frames"
@@ -226,7 +290,7 @@ class Bench:
              "decode": {"ms": round(dec_ms, 4), "GBps": round(gbps(dec_ms), 1), "frac": round(gbps(dec_ms) / HBM_PEAK_GBPS, 4),
                         "index_ms": round(idx_ms, 4)},
              "round_trip_frac": round(2 * alg / (dt_max / steps) / 1e9 / HBM_PEAK_GBPS, 4),
-             "identical": bool(check)}
+             "identical": bool(check), "packed_sha_ok": sha_ok}
         if scan:
             r["decode"]["scan_ms"] = round(scan_ms, 4)
             r["decode"]["note"] = ("frame starts found on the device (speculative segment-parallel walk, exact by "
@@ -277,6 +341,16 @@ class Bench:
             src_codec.synth_frames(content, SEED, first, n, W, H, out=out)
 
         cols = {}
+        native = None
+        if gather_mode == "native":
+            # the C-ABI gather (csrc/dbde_gather.cpp): its own RCCL communicator; the rendezvous token is made on rank 0
+            # and handed to the other ranks through the process group that is already up
+            uid = torch.zeros(dv.GATHER_ID_BYTES, dtype=torch.uint8, device=self.dev)
+            if self.rank == 0:
+                uid.copy_(torch.from_numpy(dv.gather_unique_id()))
+            if self.dist is not None:
+                self.dist.broadcast(uid, src=0)
+            native = dv.Gather(self.codec, uid.cpu().numpy(), self.world, self.rank, root=0)
         for name, g in (("resident_ring", None), ("kernels_only", None), ("with_gather", gather_mode)):
             if name == "with_gather" and g is None:
                 continue
@@ -287,7 +361,8 @@ class Bench:
                 for k in range(2):
                     self.codec.synth_frames(content, SEED, lo + k * batch, batch, W, H, out=rts.inp[k])
             else:
-                rts = RoundTripStream(self.codec, W, H, batch, source=source, source_stream=side, gather=g)
+                rts = RoundTripStream(self.codec, W, H, batch, source=source, source_stream=side, gather=g,
+                                      native=native if g == "native" else None, world=self.world, rank=self.rank)
             self.fence()
             rounds = -(-(-(-n_total // self.world)) // batch)      # batches of the largest rank block
             try:
@@ -312,7 +387,13 @@ class Bench:
             if g:
                 cols[name]["gathered_bytes"] = r["gathered_bytes"]
                 cols[name]["GBps_into_root"] = round((r["gathered_bytes"] - r["packed_bytes"]) / sec / 1e9, 1)
+                cols[name]["exchange"] = {"native": "C-ABI dbde_hip_gather_* over librccl (ncclAllGather of the counts, grouped "
+                                                    "ncclSend/ncclRecv; rank 0 encodes into its window)",
+                                          "nccl": "torch.distributed (RCCL) all_gather + batch_isend_irecv",
+                                          "host": "gloo rehearsal through pinned host memory"}[g]
             del rts
+        if native is not None:
+            native.close()
         src_codec.close()
         return cols, (lo, hi)
 
@@ -359,6 +440,8 @@ def main():
     ap.add_argument("--only", action="store_true", help="headline leg only (profiling runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", default="native", choices=["native", "nccl", "none"],
+                    help="exchange step of the streaming legs: the C-ABI's RCCL gather (default) or torch.distributed's")
     ap.add_argument("--no-single", action="store_true", help="skip the one-frame-per-call leg")
     ap.add_argument("--no-check", action="store_true", help="(experiments) skip the round-trip parity gate")
     ap.add_argument("--dry-run", action="store_true", help="launch contract only: no GPU, no codec (CPU tests)")
@@ -415,7 +498,16 @@ def main():
     W, H = cfg["W"], cfg["H"]
     content = args.content or cfg["content"]
     gather_failed = False
-    gather_mode = None if (dist is None or args.no_gather) else ("host" if rehearsal and not rehearsal_nccl else "nccl")
+    # the exchange step: "native" = the C-ABI gather (dbde_hip_gather_*, librccl), "nccl" = the same through
+    # torch.distributed, "host" = gloo rehearsal.  One rank needs no process group for the native form.
+    if args.no_gather or args.gather == "none":
+        gather_mode = None
+    elif rehearsal and not rehearsal_nccl:
+        gather_mode = "host"
+    elif args.gather == "nccl":
+        gather_mode = "nccl" if dist is not None else None
+    else:
+        gather_mode = "native"
 
     line = {"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "unit": "frames/s",
             "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
@@ -483,20 +575,35 @@ def main():
                     c = CONFIGS[k]
                     line["configs"][str(k)] = strip(b.case(c["W"], c["H"], c["frames"], c["content"], c["layout"], sub_steps, 2))
                     line["configs"][str(k)]["workload"] = c["name"]
-        # ---- gather pipeline (N > 1): batch k's compressed bytes travel while batch k+1 is encoded -------------
-        # (the headline and the contents above are complete at this point: whatever happens in the exchange leg --
-        #  it is the one part that has only ever run over gloo -- the line still carries them)
-        if gather_mode and not args.only:
-            try:
-                cols, _ = b.stream(W, H, world * 4 * min(B, 256), min(B, 256), content, gather_mode)
-                gather_failed = b.failed_exchange
-                line["gather"] = {"kernels_only": cols["kernels_only"], "with_gather": cols["with_gather"],
-                                  "note": "streaming driver, 4 batches per rank: variable-length gather of each batch's "
-                                          "compressed bytes to rank 0 (RCCL send/recv) overlapped with the next batch's "
-                                          "encode+decode; root ingress over xGMI bounds the second column"}
-            except Exception as e:   # reported, not fatal: `value` does not depend on it
-                line["gather"] = {"error": f"{type(e).__name__}: {e}"[:400]}
-                gather_failed = True
+        # ---- gather pipeline (N > 1): BASELINE configs[4] -- the 10,000-frame 4096x3072 stream in rank blocks, batch k's
+        # compressed bytes travelling to rank 0 while batch k+1 is encoded.  The headline and the contents above are
+        # complete at this point; this leg is the one part that cannot be rehearsed on a one-GPU box (rank-to-rank RCCL
+        # traffic), so it runs under a watchdog: if a collective is never answered, rank 0 prints the line it has.
+        if gather_mode and world > 1 and not args.only:
+            c5 = CONFIGS[5]
+
+            def give_up():
+                if rank == 0:
+                    line["gather"] = {"error": "the exchange leg did not finish within 300 s (a collective was never answered)"}
+                    print(json.dumps(line), flush=True)
+
+            with Watchdog(300.0, give_up):
+                for mode in ([gather_mode, "nccl"] if gather_mode == "native" else [gather_mode]):
+                    try:
+                        cols, _ = b.stream(c5["W"], c5["H"], c5["frames"], args.batch, c5["content"], mode)
+                        gather_failed = b.failed_exchange
+                        line["gather"] = {"workload": f"BASELINE {c5['name']}: {c5['frames']} frames in rank blocks, batches of {args.batch}",
+                                          "resident_ring": cols.get("resident_ring"), "kernels_only": cols.get("kernels_only"),
+                                          "with_gather": cols.get("with_gather"),
+                                          "note": "streaming driver: variable-length gather of each batch's compressed bytes to "
+                                                  "rank 0 overlapped with the next batch's encode+decode; root ingress over xGMI "
+                                                  "(7 links) bounds the with_gather column on incompressible content"}
+                        break
+                    except Exception as e:   # reported, not fatal: `value` does not depend on it
+                        line.setdefault("gather_errors", []).append(f"{mode}: {type(e).__name__}: {e}"[:400])
+                        if mode == "nccl" or gather_mode != "native":
+                            line["gather"] = {"error": line["gather_errors"][-1]}
+                            gather_failed = True
         if rank == 0 and world == 1 and not args.no_single and not args.only:
             line["single_frame"] = b.single_frame(4096, 3072, "noise8")
             line["single_frame"]["mixed_us_per_round_trip"] = b.single_frame(4096, 3072, "mixed")["us_per_round_trip"]
@@ -504,7 +611,7 @@ def main():
     if rank == 0:
         if not args.no_cpu and world == 1 and not args.only:
             progress("cpu baseline")
-            mk = lambda n: b.codec.synth_frames("noise8", SEED, 0, n, 4096, 3072).cpu().numpy()
+            mk = lambda content, n: b.codec.synth_frames(content, SEED, 0, n, 4096, 3072).cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(mk, 4096, 3072)
         print(json.dumps(line), flush=True)
     if dist is not None:

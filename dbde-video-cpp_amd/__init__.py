@@ -46,6 +46,9 @@ C_ABI_SYMBOLS = [
     "dbde16_hip_max_frame_bytes", "dbde16_hip_encode_frames", "dbde16_hip_decode_frames",
     "dbde_hip_writer_open", "dbde_hip_writer_put", "dbde_hip_writer_error", "dbde_hip_writer_close",
     "dbde_hip_reader_open", "dbde_hip_reader_next", "dbde_hip_reader_close",
+    "dbde_hip_gather_unique_id", "dbde_hip_gather_create", "dbde_hip_gather_attach", "dbde_hip_gather_destroy",
+    "dbde_hip_gather_error", "dbde_hip_gather_set_max_message", "dbde_hip_gather_begin", "dbde_hip_gather_post",
+    "dbde_hip_gather_join", "dbde_hip_gather_sync", "dbde_hip_gather_rccl_version", "dbde_hip_gather_plan",
 ]
 
 
@@ -68,6 +71,16 @@ class VideoHeader(C.Structure):
 
 class FrameResult(C.Structure):
     _fields_ = [("header", FrameHeader), ("consumed", C.c_uint64)]
+
+
+class GatherOp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("kind", C.c_int32), ("segment_offset", C.c_uint64),
+                ("window_offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+GATHER_SEND, GATHER_RECV, GATHER_OWN = 1, 2, 3
+GATHER_LOOPBACK = 1
+GATHER_ID_BYTES = 128
 
 
 u8p = C.POINTER(C.c_uint8)
@@ -164,6 +177,30 @@ def lib():
     L.dbde_hip_reader_next.argtypes = [vp, vp, i, C.POINTER(FrameHeader), C.POINTER(i)]
     L.dbde_hip_reader_close.restype = None
     L.dbde_hip_reader_close.argtypes = [vp]
+    L.dbde_hip_gather_unique_id.restype = i
+    L.dbde_hip_gather_unique_id.argtypes = [vp]
+    L.dbde_hip_gather_create.restype = i
+    L.dbde_hip_gather_create.argtypes = [vp, vp, i, i, i, C.POINTER(vp)]
+    L.dbde_hip_gather_attach.restype = i
+    L.dbde_hip_gather_attach.argtypes = [vp, vp, i, i, i, C.POINTER(vp)]
+    L.dbde_hip_gather_destroy.restype = None
+    L.dbde_hip_gather_destroy.argtypes = [vp]
+    L.dbde_hip_gather_error.restype = C.c_char_p
+    L.dbde_hip_gather_error.argtypes = [vp]
+    L.dbde_hip_gather_set_max_message.restype = i
+    L.dbde_hip_gather_set_max_message.argtypes = [vp, u64]
+    L.dbde_hip_gather_begin.restype = i
+    L.dbde_hip_gather_begin.argtypes = [vp, i, vp, vp]
+    L.dbde_hip_gather_post.restype = i
+    L.dbde_hip_gather_post.argtypes = [vp, i, vp, vp, sz, C.POINTER(u64), C.c_uint32]
+    L.dbde_hip_gather_join.restype = i
+    L.dbde_hip_gather_join.argtypes = [vp, i]
+    L.dbde_hip_gather_sync.restype = i
+    L.dbde_hip_gather_sync.argtypes = [vp, i]
+    L.dbde_hip_gather_rccl_version.restype = i
+    L.dbde_hip_gather_rccl_version.argtypes = []
+    L.dbde_hip_gather_plan.restype = i
+    L.dbde_hip_gather_plan.argtypes = [i, i, i, C.POINTER(u64), u64, C.POINTER(GatherOp), i, C.POINTER(u64)]
     _lib = L
     return L
 
@@ -174,6 +211,28 @@ def max_frame_bytes(W, H):
 
 def tiles(W, H):
     return ((W + 7) // 8) * ((H + 7) // 8)
+
+
+def gather_plan(nranks, rank, root, sizes, max_piece=0):
+    """dbde_hip_gather_plan: the ordered transfers of `rank` given every rank's byte count (host arithmetic only).
+    -> (list of (peer, kind, segment_offset, window_offset, bytes), total bytes)."""
+    arr = (C.c_uint64 * nranks)(*[int(x) for x in sizes])
+    total = C.c_uint64(0)
+    n = lib().dbde_hip_gather_plan(nranks, rank, root, arr, max_piece, None, 0, C.byref(total))
+    if n < 0:
+        raise ValueError(f"dbde_hip_gather_plan({nranks}, {rank}, {root}) -> {n}")
+    ops = (GatherOp * max(n, 1))()
+    lib().dbde_hip_gather_plan(nranks, rank, root, arr, max_piece, ops, n, None)
+    return [(o.peer, o.kind, o.segment_offset, o.window_offset, o.bytes) for o in ops[:n]], total.value
+
+
+def gather_unique_id():
+    """Rendezvous token of the native gather (ncclGetUniqueId), as a 128-byte uint8 numpy array."""
+    out = np.zeros(GATHER_ID_BYTES, np.uint8)
+    rc = lib().dbde_hip_gather_unique_id(out.ctypes.data)
+    if rc != OK:
+        raise RuntimeError(f"dbde_hip_gather_unique_id failed ({rc}): librccl could not be opened")
+    return out
 
 
 # ---- header wire format (host only) ------------------------------------------------------
@@ -412,6 +471,61 @@ class Codec:
         n = (C.c_uint64 * 4)()
         self._check(self.L.dbde_hip_timing_read(self.h, ms, n, 1 if reset else 0), "dbde_hip_timing_read")
         return {"encode": (ms[0], n[0]), "decode_index": (ms[1], n[1]), "decode": (ms[2], n[2]), "scan": (ms[3], n[3])}
+
+
+class Gather:
+    """dbde_hip_gather_*: this rank's end of the variable-length gather of the compressed stream (RCCL).
+    `unique_id`: 128 uint8 (gather_unique_id() on one rank, handed to the others), or pass `comm`=an ncclComm_t."""
+
+    def __init__(self, codec, unique_id, nranks, rank, root=0, comm=None, max_message_bytes=None):
+        self.codec, self.nranks, self.rank, self.root = codec, nranks, rank, root
+        self.h = C.c_void_p()
+        if comm is not None:
+            rc = codec.L.dbde_hip_gather_attach(codec.h, C.c_void_p(comm), nranks, rank, root, C.byref(self.h))
+        else:
+            uid = np.ascontiguousarray(np.asarray(unique_id, np.uint8))
+            assert uid.size == GATHER_ID_BYTES
+            rc = codec.L.dbde_hip_gather_create(codec.h, uid.ctypes.data, nranks, rank, root, C.byref(self.h))
+        if rc != OK or not self.h.value:
+            raise DbdeError(f"dbde_hip_gather_create failed ({rc})")
+        if max_message_bytes:
+            self._check(codec.L.dbde_hip_gather_set_max_message(self.h, int(max_message_bytes)), "set_max_message")
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise DbdeError(f"dbde_hip_gather_{what} failed ({rc}): {self.codec.L.dbde_hip_gather_error(self.h).decode()}")
+
+    def begin(self, slot, last_offset, last_bytes):
+        """last_offset / last_bytes: 1-element int64 device tensors (views of the encoder's outputs) or None."""
+        self._check(self.codec.L.dbde_hip_gather_begin(self.h, slot, last_offset.data_ptr() if last_offset is not None else None,
+                                                       last_bytes.data_ptr() if last_bytes is not None else None), "begin")
+
+    def post(self, slot, segment, segment_offset, window, window_offset, window_bytes, loopback=False):
+        """-> list of every rank's byte count.  segment / window: uint8 device tensors (either may be None where the
+        rank does not need it)."""
+        sizes = (C.c_uint64 * self.nranks)()
+        seg = segment.data_ptr() + segment_offset if segment is not None else None
+        win = window.data_ptr() + window_offset if window is not None else None
+        self._check(self.codec.L.dbde_hip_gather_post(self.h, slot, seg, win, window_bytes, sizes,
+                                                      GATHER_LOOPBACK if loopback else 0), "post")
+        return [int(x) for x in sizes]
+
+    def join(self, slot):
+        self._check(self.codec.L.dbde_hip_gather_join(self.h, slot), "join")
+
+    def sync(self, slot):
+        self._check(self.codec.L.dbde_hip_gather_sync(self.h, slot), "sync")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.codec.L.dbde_hip_gather_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FileWriter:

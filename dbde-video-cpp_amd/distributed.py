@@ -51,7 +51,8 @@ def gather_stream_begin(segment, nbytes, dst=0, group=None, out=None, max_messag
         at, ops = 0, []
         for r in range(world):
             if r == rank:
-                out[at:at + sizes[r]].copy_(segment[:sizes[r]], non_blocking=True)
+                if out.data_ptr() + at != segment.data_ptr():    # (a root that produced its segment in place has nothing to move)
+                    out[at:at + sizes[r]].copy_(segment[:sizes[r]], non_blocking=True)
             else:
                 for o, n in _pieces(sizes[r], piece):
                     ops.append(dist.P2POp(dist.irecv, out[at + o:at + o + n], r, group))

@@ -6,8 +6,11 @@ batches through two input slots and two stream slots, and three things overlap o
 
     source stream : frames of batch k+2 are produced into the input slot batch k has just left
     codec stream  : encode batch k+1 (-> concatenated .dbde body) and decode it back (the round trip)
-    comm stream   : the compressed bytes of batch k travel to the root (RCCL send/recv over xGMI,
-                    distributed.gather_stream_begin/_end), into one of two root windows
+    comm stream   : the compressed bytes of batch k travel to the root (RCCL send/recv over xGMI) into one of two
+                    root windows -- gather="native": the C-ABI's dbde_hip_gather_* (csrc/dbde_gather.cpp: byte counts
+                    exchanged device to device, rank 0 encodes straight into its window, no host stall on the codec
+                    stream); gather="nccl": the same exchange through torch.distributed
+                    (distributed.gather_stream_begin/_end)
 
 The host never waits on the codec stream: the byte count of batch k (needed to post matching send/recv
 pieces) is read through a side stream that waits only on batch k's encode event, while batch k+1 is already
@@ -28,11 +31,13 @@ class RoundTripStream:
     source  : callable(first_frame, n, out_tensor) that ENQUEUES the production of n frames on
               `source_stream` (e.g. synth_frames of a second Codec created on that stream), or None to re-use
               what is in the input slots (caller filled them: a ring of resident frames)
-    gather  : None | "nccl" | "host": send every batch's compressed bytes to rank 0 ("host": staged through
-              pinned memory, for gloo rehearsals)
+    gather  : None | "native" | "nccl" | "host": send every batch's compressed bytes to rank 0 ("native": the
+              C-ABI gather, `native` = a dbde_video_cpp_amd.Gather; "host": staged through pinned memory, for gloo
+              rehearsals)
     """
 
-    def __init__(self, codec, W, H, batch, source=None, source_stream=None, gather=None, decode=True, check=False):
+    def __init__(self, codec, W, H, batch, source=None, source_stream=None, gather=None, decode=True, check=False,
+                 native=None, world=1, rank=0, loopback=False, tap=None):
         self.codec, self.W, self.H, self.batch = codec, W, H, batch
         self.source, self.gather, self.decode, self.check = source, gather, decode, check
         dev = codec.device
@@ -54,6 +59,17 @@ class RoundTripStream:
         self.ev_copy = torch.cuda.Event()
         self.window = None
         self.mismatches = 0
+        self.native, self.loopback = native, loopback
+        self.tap = tap      # tests: callable(k, slot, n), called on the codec stream right after batch k's encode is enqueued
+        if gather == "native":
+            assert native is not None, 'gather="native" needs a Gather'
+        if gather in ("native", "nccl") and rank == 0:
+            # the root's two windows: every rank's worst case; rank 0's own segment is ENCODED here (its displacement
+            # in the gathered stream is 0), so the root never copies its own bytes
+            lead, cap = self.out[0][1], self.out[0][2]
+            self.window = [torch.empty(lead + world * cap + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+            if not loopback:
+                self.out = [(self.window[k], lead, cap) for k in range(2)]
 
     def _produce(self, slot, first, n):
         if self.source is None:
@@ -85,12 +101,20 @@ class RoundTripStream:
             return nbytes, sum(sizes)
         with torch.cuda.stream(self.s_comm):
             self.s_comm.wait_event(self.ev_enc[slot])
-            if rank == 0 and self.window is None:
-                self.window = [torch.empty(world * (cap + 64), dtype=torch.uint8, device=self.dev) for _ in range(2)]
-            _, sizes, works = dd.gather_stream_begin(seg, nbytes, dst=0, out=self.window[slot] if rank == 0 else None)
+            _, sizes, works = dd.gather_stream_begin(seg, nbytes, dst=0, out=self.window[slot][lead:] if rank == 0 else None)
             dd.gather_stream_end(works)
             self.ev_gath[slot].record(self.s_comm)
         return nbytes, sum(sizes)
+
+    def _native_begin(self, slot, n):
+        last = slice(n - 1, n)
+        self.native.begin(slot, self.offs[slot][last] if n else None, self.sizes[slot][last] if n else None)
+
+    def _native_post(self, slot, world):
+        buf, lead, cap = self.out[slot]
+        win = self.window[slot] if self.window is not None else None
+        sizes = self.native.post(slot, buf, lead, win, lead, world * cap, loopback=self.loopback)
+        return sizes[self.native.rank], sum(sizes)
 
     def run(self, first_frame, n_frames, world=1, rank=0, rounds=None):
         """Returns a dict: frames, seconds (host wall, everything drained), packed bytes of this rank,
@@ -98,7 +122,9 @@ class RoundTripStream:
         part in (the batch count of the LARGEST rank block; a rank with fewer batches posts empty ones)."""
         codec, W, H, B = self.codec, self.W, self.H, self.batch
         nb = (n_frames + B - 1) // B
-        count = lambda k: min(B, n_frames - k * B)
+        native = self.gather == "native"
+        rounds = max(rounds or nb, nb) if self.gather else nb
+        count = lambda k: max(0, min(B, n_frames - k * B))
         for ev in self.ev_enc + self.ev_gath:
             ev.record(self.s_codec)
         for k in range(min(2, nb)):
@@ -106,32 +132,42 @@ class RoundTripStream:
         packed = gathered = 0
         torch.cuda.synchronize(self.dev)      # the first two batches are resident when the clock starts
         t0 = time.perf_counter()
-        for k in range(nb):
+        # Every rank walks the same `rounds` iterations, so that the collective calls (size exchange of round k, then
+        # the transfers of round k-1) are issued in the same order everywhere; a rank whose block has fewer batches
+        # takes part in the remaining rounds with nothing to send.
+        for k in range(rounds):
             slot, n = k % 2, count(k)
             buf, lead, cap = self.out[slot]
             with torch.cuda.stream(self.s_codec):
-                if self.source is not None:
-                    self.s_codec.wait_event(self.ev_src[slot])
-                self.s_codec.wait_event(self.ev_gath[slot])          # the gather that read this stream slot is done
-                codec.encode_frames(self.inp[slot], W, H, n, buf, lead, cap, first_index=first_frame + k * B,
-                                    offsets=self.offs[slot], nbytes=self.sizes[slot])
-                self.ev_enc[slot].record(self.s_codec)
-                if self.decode:
+                if n:
+                    if self.source is not None:
+                        self.s_codec.wait_event(self.ev_src[slot])
+                    if native:
+                        self.native.join(slot)                           # the transfer that read this slot is done
+                    else:
+                        self.s_codec.wait_event(self.ev_gath[slot])
+                    codec.encode_frames(self.inp[slot], W, H, n, buf, lead, cap, first_index=first_frame + k * B,
+                                        offsets=self.offs[slot], nbytes=self.sizes[slot])
+                    self.ev_enc[slot].record(self.s_codec)
+                    if self.tap is not None:
+                        self.tap(k, slot, n)
+                if native:
+                    self._native_begin(slot, n)      # size exchange enqueued behind the encode; returns at once
+                if n and self.decode:
                     codec.decode_frames(buf, lead, cap, self.offs[slot], W, H, n, images=self.img, results=self.res)
                     if self.check:
                         self.mismatches += int((self.img[:n] != self.inp[slot][:n]).any().item())
             if k + 2 < nb:
                 self._produce(slot, first_frame + (k + 2) * B, count(k + 2))
-            if self.gather and k >= 1:
-                a, b = self._post_gather((k - 1) % 2, count(k - 1), world, rank)
+            if self.gather and k >= 1:       # one round behind: the host wait for the counts ends early
+                a, b = self._native_post((k - 1) % 2, world) if native else self._post_gather((k - 1) % 2, count(k - 1), world, rank)
                 packed, gathered = packed + a, gathered + b
-        if self.gather:
-            if nb:     # (a rank whose block is empty -- fewer frames than ranks -- only posts the empty rounds below)
-                a, b = self._post_gather((nb - 1) % 2, count(nb - 1), world, rank)
-                packed, gathered = packed + a, gathered + b
-            for _ in range(nb, rounds or nb):          # blocks differ by a frame: keep the collective calls in step
-                a, b = self._post_gather((nb - 1) % 2, 0, world, rank)
-                gathered += b
+        if self.gather and rounds:
+            a, b = self._native_post((rounds - 1) % 2, world) if native else self._post_gather((rounds - 1) % 2, count(rounds - 1), world, rank)
+            packed, gathered = packed + a, gathered + b
+        if native:
+            for slot in range(2):
+                self.native.sync(slot)
         torch.cuda.synchronize(self.dev)
         dt = time.perf_counter() - t0
         codec.sync()

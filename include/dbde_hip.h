@@ -241,6 +241,72 @@ int dbde16_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t 
                              const uint64_t *d_frame_offsets, int W, int H, int n_frames,
                              uint16_t *d_images, dbde_hip_frame_result *d_results);
 
+/* ---- multi-GPU: variable-length gather of the compressed stream to a root (RCCL over xGMI) ------------------- */
+/* Frames are independent, so the path shards by contiguous frame blocks (rank g of G owns frames
+ * [g*N/G, (g+1)*N/G)): every rank encodes its block with dbde_hip_encode_frames (slot_stride 0) and its output is
+ * one in-order segment of the final stream (README.md:12-23: frames simply follow each other).  The only exchange
+ * step is this gather (the reference is single-threaded and has no counterpart).  RCCL has no gatherv: byte counts
+ * are all-gathered (ncclAllGather, 8 bytes per rank), every rank derives the same displacements, and the bytes
+ * travel as grouped ncclSend / ncclRecv into the root's window at their displacement.  One process per GPU; the
+ * library opens librccl itself (dlopen; a process that never calls these needs no RCCL).
+ *
+ * Per batch, with two slots so that the gather of batch k overlaps the encode of batch k+1:
+ *   dbde_hip_gather_join(g, slot)            codec stream waits until the slot's previous transfer has finished
+ *   dbde_hip_encode_frames(... d_frame_offsets, d_frame_bytes)        (root 0: straight into its window)
+ *   dbde_hip_gather_begin(g, slot, &d_frame_offsets[n-1], &d_frame_bytes[n-1])     returns at once
+ *   ... enqueue more work (decode, the next batch's encode) ...
+ *   dbde_hip_gather_post(g, slot, d_segment, d_window, window_bytes, sizes, 0)     host waits for the counts only
+ * Collective: every rank of the communicator makes the same begin / post calls in the same order. */
+typedef struct dbde_hip_gather dbde_hip_gather;
+#define DBDE_HIP_GATHER_ID_BYTES 128
+/* Rendezvous token (ncclGetUniqueId): one rank creates it, the caller hands it to every other rank by any means. */
+int dbde_hip_gather_unique_id(uint8_t id[DBDE_HIP_GATHER_ID_BYTES]);
+/* Rank `rank` of `nranks` on the context's device; `root` receives.  Collective (ncclCommInitRank). */
+int dbde_hip_gather_create(dbde_hip_ctx *ctx, const uint8_t id[DBDE_HIP_GATHER_ID_BYTES], int nranks, int rank,
+                           int root, dbde_hip_gather **out);
+/* The same on a communicator the caller already owns (an ncclComm_t, passed as void*); it is not destroyed. */
+int dbde_hip_gather_attach(dbde_hip_ctx *ctx, void *nccl_comm, int nranks, int rank, int root,
+                           dbde_hip_gather **out);
+void dbde_hip_gather_destroy(dbde_hip_gather *g);
+const char *dbde_hip_gather_error(const dbde_hip_gather *g);
+/* Messages are cut into pieces of at most this many bytes (default 1 GiB), all posted in one group. */
+int dbde_hip_gather_set_max_message(dbde_hip_gather *g, uint64_t bytes);
+/* Enqueues the size exchange of `slot` (0 or 1) behind everything on the context's stream: this rank's byte count
+ * is the sum of the two DEVICE words (either may be NULL = 0; the encoder's offset and length of the batch's last
+ * frame).  Does not wait for anything. */
+int dbde_hip_gather_begin(dbde_hip_gather *g, int slot, const uint64_t *d_last_offset,
+                          const uint64_t *d_last_bytes);
+/* Blocks the HOST (not the codec's stream) until the slot's counts have arrived, then posts the transfers on the
+ * gather's own stream: a non-root rank sends d_segment[0, its count) to the root; the root receives rank r's bytes
+ * at d_window + sum(counts of ranks < r).  The root's own bytes are not moved when d_segment already is
+ * d_window + its displacement (root 0 encoding straight into its window), else copied once device-to-device.
+ * window_bytes (root) must hold the sum of all counts -- size it as nranks x the per-rank capacity: a root that
+ * returns DBDE_HIP_ERR_CAPACITY has posted nothing and its peers' sends stay unmatched.  sizes_out: optional host
+ * array of nranks counts.  flags: DBDE_HIP_GATHER_LOOPBACK (tests and one-GPU rehearsals) sends the root's own
+ * segment to itself through ncclSend / ncclRecv instead. */
+#define DBDE_HIP_GATHER_LOOPBACK 1u
+int dbde_hip_gather_post(dbde_hip_gather *g, int slot, const uint8_t *d_segment, uint8_t *d_window,
+                         size_t window_bytes, uint64_t *sizes_out, uint32_t flags);
+/* Makes the context's stream wait for the slot's posted transfers (before its segment / window is overwritten). */
+int dbde_hip_gather_join(dbde_hip_gather *g, int slot);
+/* Blocks the host until they have finished (before the root reads the window from the host side). */
+int dbde_hip_gather_sync(dbde_hip_gather *g, int slot);
+/* NCCL_VERSION_CODE of the RCCL in use; 0 when librccl cannot be opened. */
+int dbde_hip_gather_rccl_version(void);
+/* The transfer plan, exposed because it is the host logic both ends must agree on (pure arithmetic, no GPU):
+ * for `rank`, the ordered list of operations given every rank's count.  Returns the number of operations
+ * (filling at most max_ops of them) or a negative error; *total_out = sum of counts. */
+enum { DBDE_HIP_GATHER_SEND = 1, DBDE_HIP_GATHER_RECV = 2, DBDE_HIP_GATHER_OWN = 3 };
+typedef struct {
+    int32_t peer;              /* rank at the other end (OWN: the root itself) */
+    int32_t kind;              /* DBDE_HIP_GATHER_SEND / _RECV / _OWN */
+    uint64_t segment_offset;   /* SEND: byte offset in this rank's segment */
+    uint64_t window_offset;    /* byte offset in the root's window (displacement + piece offset) */
+    uint64_t bytes;
+} dbde_hip_gather_op;
+int dbde_hip_gather_plan(int nranks, int rank, int root, const uint64_t *sizes, uint64_t max_piece,
+                         dbde_hip_gather_op *ops, int max_ops, uint64_t *total_out);
+
 /* ---- kernel timing hook for bench.py ---------------------------------------------------- */
 /* When enabled, every encode / decode call brackets its kernels with HIP events on the
  * context's stream; dbde_hip_timing_read returns accumulated milliseconds and launch counts

@@ -49,3 +49,31 @@ def test_c_client_runs(tmp_path):
     golden = arrays[readme["name"] + ".packed"].tobytes().hex()   # produced by the real reference
     r = subprocess.run([exe, image, golden], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.stdout, r.stderr)
+
+
+GATHER_SRC = os.path.join(ROOT, "tests", "c_client", "gather1.cpp")
+
+
+def _build_gather(tmp_path):
+    import dbde_video_cpp_amd as dv
+    if not os.path.exists(dv.LIB_PATH):
+        dv.build()
+    exe = str(tmp_path / "gather1")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-I", os.path.join(ROOT, "include"), GATHER_SRC,
+                    "-L", dv.PKG_DIR, "-ldbde_hip", "-Wl,-rpath," + dv.PKG_DIR, "-o", exe], check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_gather_client_builds(tmp_path):
+    exe = _build_gather(tmp_path)
+    out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    assert "dbde_hip_gather_post" in out and "nccl" not in out, "the caller needs the C-ABI only, not RCCL itself"
+
+
+@pytest.mark.gpu
+def test_gather_client_runs_one_rank_rccl(tmp_path):
+    """The native gather at nranks = 1 from a process without Python or torch: RCCL communicator, size all-gather,
+    in-place root segment, and the ncclSend / ncclRecv path in loopback (tests/c_client/gather1.cpp)."""
+    exe = _build_gather(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])

@@ -71,6 +71,7 @@ struct dbde_hip_ctx {
     uint32_t exp_flags = 0;          // $DBDE_HIP_EXPERIMENT (tuning experiments only)
     uint32_t enc_grid = 0;           // resident workgroups for the persistent encoder
     uint32_t enc16_grid = 0;         // the same for the DBDE16 encoder (queried at its first call)
+    uint32_t enc_rows_grid = 0;      // the same for the frame-sequential encoder (odd widths, one slot per frame)
     int n_cu = 0;
     uint64_t *diag = nullptr;        // [16] phase cycle sums of diagnostic launches
     bool timing = false;
@@ -270,6 +271,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     }
     const uint64_t n_chunks64 = (uint64_t)n_frames * enc_cpf;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: too many chunks in one call");
+    const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
     if (slot_stride) {
         if (slot_stride < maxf) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: slot_stride below the worst case");
         if ((uint64_t)(n_frames - 1) * slot_stride + maxf > out_capacity)
@@ -282,6 +284,29 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
             return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: more than 2^32 payload words possible; split the batch");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // Widths that are not multiples of 16, one slot per frame: a frame's bytes then depend on nothing outside the frame,
+    // and the frame-sequential encoder applies (encode_rows_kernel: a workgroup owns whole frames, pixels staged by
+    // LDS-DMA, no workspace).  It needs frames to deal out: taken when the last round of frames over its resident
+    // workgroups is at least 85 % full ($DBDE_HIP_EXPERIMENT bit 1 forces it for any count -- tests; bit 2 disables it).
+    if (!fast_in && slot_stride != 0 && aligned_out && g.w >= 64u && !(ctx->exp_flags & 4u)) {
+        if (!ctx->enc_rows_grid) ctx->enc_rows_grid = (uint32_t)(encode_rows_blocks_per_cu() * ctx->n_cu);
+        const uint64_t G = ctx->enc_rows_grid, rounds = ((uint64_t)n_frames + G - 1) / G;
+        if ((ctx->exp_flags & 2u) || (uint64_t)n_frames * 100u >= rounds * G * 85u) {
+            EncParams p;
+            memset(&p, 0, sizeof p);
+            p.images = d_images; p.out = d_out;
+            p.frame_offsets = d_frame_offsets; p.frame_bytes = d_frame_bytes;
+            p.indices = d_indices; p.elapsed_ns = d_elapsed_ns; p.first_index = first_index;
+            p.sticky = ctx->sticky;
+            p.slot_stride = slot_stride; p.frame_pixels = g.pixels;
+            p.W = W; p.H = H; p.w = g.w; p.h = g.h; p.T = g.T;
+            span_begin(ctx, 0);
+            HIP_TRY(ctx, launch_encode_rows(p, (uint32_t)n_frames, ctx->enc_rows_grid, ctx->stream));
+            span_end(ctx);
+            return DBDE_HIP_OK;
+        }
+    }
 
     const uint32_t n_chunks = (uint32_t)n_chunks64;
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
@@ -324,8 +349,6 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.flags = ctx->exp_flags;
     p.grid_blocks = ctx->enc_grid;
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
-    const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) &&
-                             (slot_stride % 8 == 0);
     if (small) HIP_TRY(ctx, launch_encode_small(p, fast_in, aligned_out, ctx->stream));
     else HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
     span_end(ctx);

@@ -132,6 +132,10 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
 // self-cleaning workspace (records and counters are zero on entry and on exit).
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
+// Frame-sequential encoder for widths that are not multiples of 16 (one slot per frame, aligned output, w >= 64 tiles
+// across): a workgroup owns whole frames, pixels are staged by LDS-DMA; no workspace.  grid_blocks: resident workgroups.
+hipError_t launch_encode_rows(const EncParams &p, uint32_t n_frames, uint32_t grid_blocks, hipStream_t s);
+int encode_rows_blocks_per_cu();
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
 // self_index: no index kernel ran; every workgroup validates the frame and finds its offset itself (few frames)

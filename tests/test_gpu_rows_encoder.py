@@ -1,0 +1,107 @@
+"""GPU: the frame-sequential encoder (encode_rows_kernel, csrc/dbde_kernels.hip) -- widths that are not multiples of
+16, one slot per frame: a workgroup owns whole frames, pixels arrive by LDS-DMA as aligned blocks and are read back at
+their byte offset.  The C-ABI takes it by itself when there are enough frames to deal out; here it is FORCED for any
+frame count ($DBDE_HIP_EXPERIMENT bit 1) and every frame is compared byte for byte with the oracle: strips that
+straddle two tile rows, partial right-edge tiles (dbde_util.cpp:116-128), bottom padding (:129-132), the last chunk of
+a frame with idle waves, several frames per workgroup, explicit indices / elapsed_ns."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0xDBDE2016
+
+
+@pytest.fixture(scope="module")
+def dv():
+    import dbde_video_cpp_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def rows_codec(dv):
+    os.environ["DBDE_HIP_EXPERIMENT"] = "2"
+    try:
+        c = dv.Codec(0)
+    finally:
+        os.environ.pop("DBDE_HIP_EXPERIMENT", None)
+    yield c
+    c.close()
+
+
+def _encode_slots(codec, imgs, W, H, n, first_index=0, **kw):
+    import torch
+    slot = ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
+    buf, lead, cap = codec.alloc_stream(W, H, n, slot_stride=slot)
+    buf.fill_(0xEE)
+    offs, sizes = codec.encode_frames(imgs, W, H, n, buf, lead, cap, first_index=first_index, slot_stride=slot, **kw)
+    codec.sync()
+    o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+    assert all(o[f] == f * slot for f in range(n))
+    return buf, lead, cap, slot, offs, sizes, o, s
+
+
+@pytest.mark.parametrize("W,H,n", [(513, 17, 3), (520, 9, 2), (1001, 33, 5), (1025, 64, 2), (2047, 8, 3), (4095, 24, 2),
+                                   (1921, 1081, 2), (8200, 9, 2), (777, 777, 1), (515, 1, 4)])
+@pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
+def test_rows_encoder_matches_oracle(rows_codec, oracle, W, H, n, mode):
+    import torch
+    codec = rows_codec
+    imgs = codec.synth_frames(mode, SEED, 100, n, W, H)
+    imgs_h = imgs.cpu().numpy()
+    buf, lead, cap, slot, offs, sizes, o, s = _encode_slots(codec, imgs, W, H, n, first_index=100)
+    host = buf.cpu().numpy()
+    for f in range(n):
+        want = oracle.pack_frame(100 + f, imgs_h[f], W, H)
+        assert s[f] == len(want), (W, H, mode, f)
+        assert host[lead + o[f]: lead + o[f] + s[f]].tobytes() == want.tobytes(), (W, H, mode, f)
+        assert (host[lead + o[f] + s[f]: lead + min(o[f] + slot, cap)] == 0xEE).all(), "wrote past the frame"
+    assert (host[:lead] == 0xEE).all()
+    back, res = codec.decode_frames(buf, lead, cap, offs, W, H, n)
+    codec.sync()
+    assert torch.equal(back, imgs)
+
+
+def test_rows_encoder_many_frames_per_workgroup(rows_codec, oracle):
+    """More frames than resident workgroups: every workgroup walks several frames (f, f + G, ...), with explicit frame
+    numbers and elapsed_ns (trap T1: F64 on the wire)."""
+    import torch
+    codec = rows_codec
+    W, H, n = 513, 17, 1300
+    imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+    idx = torch.arange(n, dtype=torch.int64, device=imgs.device) * 3 + 7
+    el = torch.arange(n, dtype=torch.int64, device=imgs.device) * 1000000007
+    buf, lead, cap, slot, offs, sizes, o, s = _encode_slots(codec, imgs, W, H, n, indices=idx, elapsed_ns=el)
+    host = buf.cpu().numpy()
+    imgs_h = imgs.cpu().numpy()
+    for f in range(n):
+        want = oracle.pack_frame(3 * f + 7, imgs_h[f], W, H)
+        want[:20] = oracle.pack_frame_header(2, 3 * f + 7, 1000000007 * f)
+        assert host[lead + o[f]: lead + o[f] + s[f]].tobytes() == want.tobytes(), f
+    back, res = codec.decode_frames(buf, lead, cap, offs, W, H, n)
+    codec.sync()
+    assert torch.equal(back, imgs)
+    rr = codec.parse_results(res)
+    assert all(rr[f][:2] == (2, 3 * f + 7) for f in range(n))
+
+
+@pytest.mark.parametrize("mode", ["noise8", "mixed"])
+def test_rows_encoder_default_selection_config4(dv, golden, mode):
+    """BASELINE configs[3] as bench.py runs it (slots, 512 frames = one full round of workgroups): the library picks
+    the frame-sequential encoder by itself; frames 0 and 3 against the SHA-256 of the reference's own output."""
+    import torch
+    manifest, _ = golden
+    codec = dv.Codec(0)
+    W, H, n = 1921, 1081, 512
+    imgs = codec.synth_frames(mode, SEED, 0, n, W, H)
+    buf, lead, cap, slot, offs, sizes, o, s = _encode_slots(codec, imgs, W, H, n)
+    for e in [e for e in manifest["big"] if e["name"] == "cfg4_1921x1081" and e["mode"] == mode]:
+        f = e["frame"]
+        got = buf[lead + int(o[f]): lead + int(o[f] + s[f])].cpu().numpy()
+        assert len(got) == e["packed_bytes"] and hashlib.sha256(got.tobytes()).hexdigest() == e["packed_sha"], (mode, f)
+    back, res = codec.decode_frames(buf, lead, cap, offs, W, H, n)
+    codec.sync()
+    assert torch.equal(back, imgs)
+    codec.close()

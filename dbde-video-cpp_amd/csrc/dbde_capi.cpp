@@ -71,7 +71,6 @@ struct dbde_hip_ctx {
     uint32_t exp_flags = 0;          // $DBDE_HIP_EXPERIMENT (tuning experiments only)
     uint32_t enc_grid = 0;           // resident workgroups for the persistent encoder
     uint32_t enc16_grid = 0;         // the same for the DBDE16 encoder (queried at its first call)
-    uint32_t enc_rows_grid = 0;      // the same for the frame-sequential encoder (odd widths, one slot per frame)
     int n_cu = 0;
     uint64_t *diag = nullptr;        // [16] phase cycle sums of diagnostic launches
     bool timing = false;
@@ -285,30 +284,49 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    // Widths that are not multiples of 16, one slot per frame: a frame's bytes then depend on nothing outside the frame,
-    // and the frame-sequential encoder applies (encode_rows_kernel: a workgroup owns whole frames, pixels staged by
-    // LDS-DMA, no workspace).  It needs frames to deal out: taken when the last round of frames over its resident
-    // workgroups is at least 85 % full ($DBDE_HIP_EXPERIMENT bit 1 forces it for any count -- tests; bit 2 disables it).
-    if (!fast_in && slot_stride != 0 && aligned_out && g.w >= 64u && !(ctx->exp_flags & 4u)) {
-        if (!ctx->enc_rows_grid) ctx->enc_rows_grid = (uint32_t)(encode_rows_blocks_per_cu() * ctx->n_cu);
-        const uint64_t G = ctx->enc_rows_grid, rounds = ((uint64_t)n_frames + G - 1) / G;
+    const uint32_t n_chunks = (uint32_t)n_chunks64;
+    EncParams p;
+    p.images = d_images;
+    p.out = d_out;
+    p.frame_offsets = d_frame_offsets;
+    p.frame_bytes = d_frame_bytes;
+    p.indices = d_indices;
+    p.elapsed_ns = d_elapsed_ns;
+    p.first_index = first_index;
+    p.sticky = ctx->sticky;
+    p.slot_stride = slot_stride;
+    p.frame_pixels = g.pixels;
+    p.W = W;
+    p.H = H;
+    p.w = g.w;
+    p.h = g.h;
+    p.T = g.T;
+    p.chunks_per_frame = enc_cpf;
+    p.lanes_per_row = lanes_per_row;
+    p.magic_w = div_magic_of(g.w);
+    p.magic_cpf = div_magic_of(enc_cpf);
+    p.magic_lpr = div_magic_of(lanes_per_row);
+    p.last_frame = (uint32_t)n_frames - 1u;
+    p.n_chunks = n_chunks;
+    p.flags = ctx->exp_flags;
+    p.grid_blocks = ctx->enc_grid;
+    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
+    p.ctrl = nullptr;
+    p.state = nullptr;
+
+    // One slot per frame: frames are independent, a workgroup per frame needs no prefix from anybody (encode_frame_kernel).
+    // Taken when the frames fill the device's workgroup slots well: at least one round of them, the last round 85 % full
+    // ($DBDE_HIP_EXPERIMENT bit 1 forces it for any count -- tests; bit 2 keeps the scan-based kernels -- A/B).
+    if (slot_stride != 0 && !(ctx->exp_flags & 4u)) {
+        const uint64_t G = ctx->enc_grid, rounds = ((uint64_t)n_frames + G - 1) / G;
         if ((ctx->exp_flags & 2u) || (uint64_t)n_frames * 100u >= rounds * G * 85u) {
-            EncParams p;
-            memset(&p, 0, sizeof p);
-            p.images = d_images; p.out = d_out;
-            p.frame_offsets = d_frame_offsets; p.frame_bytes = d_frame_bytes;
-            p.indices = d_indices; p.elapsed_ns = d_elapsed_ns; p.first_index = first_index;
-            p.sticky = ctx->sticky;
-            p.slot_stride = slot_stride; p.frame_pixels = g.pixels;
-            p.W = W; p.H = H; p.w = g.w; p.h = g.h; p.T = g.T;
             span_begin(ctx, 0);
-            HIP_TRY(ctx, launch_encode_rows(p, (uint32_t)n_frames, ctx->enc_rows_grid, ctx->stream));
+            HIP_TRY(ctx, launch_encode_frame(p, (uint32_t)n_frames, fast_in, aligned_out, ctx->stream));
             span_end(ctx);
             return DBDE_HIP_OK;
         }
     }
 
-    const uint32_t n_chunks = (uint32_t)n_chunks64;
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
     {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
         const size_t had = ctx->lb_bytes;
@@ -325,30 +343,8 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     else if (!ctx->lb_clean) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
     ctx->lb_clean = small;
 
-    EncParams p;
-    p.images = d_images;
-    p.out = d_out;
-    p.frame_offsets = d_frame_offsets;
-    p.frame_bytes = d_frame_bytes;
-    p.indices = d_indices;
-    p.elapsed_ns = d_elapsed_ns;
-    p.first_index = first_index;
     p.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
     p.state = reinterpret_cast<unsigned long long *>(ctx->lb + 16);
-    p.sticky = ctx->sticky;
-    p.slot_stride = slot_stride;
-    p.frame_pixels = g.pixels;
-    p.W = W;
-    p.H = H;
-    p.w = g.w;
-    p.h = g.h;
-    p.T = g.T;
-    p.chunks_per_frame = enc_cpf;
-    p.lanes_per_row = lanes_per_row;
-    p.n_chunks = n_chunks;
-    p.flags = ctx->exp_flags;
-    p.grid_blocks = ctx->enc_grid;
-    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     if (small) HIP_TRY(ctx, launch_encode_small(p, fast_in, aligned_out, ctx->stream));
     else HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
     span_end(ctx);

@@ -64,6 +64,9 @@ constexpr uint32_t kEncChunkTiles = 1024;
 //         [31:0]  payload words of the whole launch up to and including this chunk (mod 2^32)
 constexpr unsigned long long kStAgg = 1ull << 62, kStInc = 2ull << 62, kStPoison = 3ull << 62;
 
+// floor(2^32 / d) for the kernels' div_magic (d = 1: 2^32 - 1, which the one correction step absorbs).
+inline uint32_t div_magic_of(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
+
 struct EncParams {
     const uint8_t *images;         // n_frames * W*H
     uint8_t *out;
@@ -84,6 +87,8 @@ struct EncParams {
     // tile row (the last lane of a row holds one tile when w is odd); a chunk is 512 consecutive pairs in stream
     // order, wherever they fall.  lanes_per_row == 0: plain runs of 1024 tiles (w even: pairs never straddle).
     uint32_t lanes_per_row;
+    uint32_t magic_w, magic_cpf, magic_lpr;   // div_magic_of(w), (chunks_per_frame), (lanes_per_row): divisions by launch constants
+    uint32_t last_frame;           // n_frames - 1: no pixel load reaches past the end of that frame
     uint32_t flags;                // bit 0: force ticket mode (A/B measurements)
     uint32_t grid_blocks;          // resident workgroups of the persistent encoder
     unsigned long long *diag;      // [16] cycle counters, written only by -DDBDE_DIAG builds (profiles/variants.sh)
@@ -132,10 +137,10 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
 // self-cleaning workspace (records and counters are zero on entry and on exit).
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
-// Frame-sequential encoder for widths that are not multiples of 16 (one slot per frame, aligned output, w >= 64 tiles
-// across): a workgroup owns whole frames, pixels are staged by LDS-DMA; no workspace.  grid_blocks: resident workgroups.
-hipError_t launch_encode_rows(const EncParams &p, uint32_t n_frames, uint32_t grid_blocks, hipStream_t s);
-int encode_rows_blocks_per_cu();
+// One slot per frame (slot_stride != 0): a workgroup per frame walks the frame's chunks in order, the in-frame prefix is
+// a running sum -- no workspace, no scanner, nothing shared between workgroups.  Worth it from about one frame per
+// resident workgroup slot (dbde_capi.cpp decides).
+hipError_t launch_encode_frame(const EncParams &p, uint32_t n_frames, bool fast_in, bool aligned_out, hipStream_t s);
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
 // self_index: no index kernel ran; every workgroup validates the frame and finds its offset itself (few frames)

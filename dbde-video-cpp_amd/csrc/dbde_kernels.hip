@@ -130,6 +130,19 @@ __device__ __forceinline__ bool in_extent(uint64_t off, uint64_t len, uint64_t e
     return off <= extent && len <= extent - off;
 }
 
+// n / d with d fixed for the launch: m = floor(2^32 / d) comes from the host (div_magic_of), the quotient estimate
+// mulhi(n, m) is the true one or one below it (n * m / 2^32 > n / d - 1 for every n < 2^32), one correction.  A u32
+// division is 30-40 vector instructions on this part and the chunk geometry needs two or three per lane and step.
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t d, uint32_t m, uint32_t &rem) {
+    uint32_t q = __umulhi(n, m);
+    uint32_t r = n - q * d;
+    const bool fix = r >= d;
+    q += fix ? 1u : 0u;
+    r -= fix ? d : 0u;
+    rem = r;
+    return q;
+}
+
 // ---------------------------------------------------------------------------------------
 // ENCODE
 // ---------------------------------------------------------------------------------------
@@ -257,8 +270,9 @@ __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
                     const uint32_t g_incl = carry_glob + incl, g_excl = g_incl - t;
                     // launch-wide prefix at the start of this lane's frame: inside the window it is
                     // the exclusive prefix of the lane holding the frame's first chunk
-                    const uint32_t f = idx / p.chunks_per_frame;
-                    const uint32_t fstart = f * p.chunks_per_frame;
+                    uint32_t cf_lane;
+                    (void)div_magic(idx, p.chunks_per_frame, p.magic_cpf, cf_lane);
+                    const uint32_t fstart = idx - cf_lane;                 // first chunk of the lane's frame
                     const uint32_t from_lane = __shfl(g_excl, fstart >= base ? (int)(fstart - base) : 0, 64);
                     const uint32_t gs = fstart >= base ? from_lane : frame_start_glob;
                     const uint32_t inf_incl = g_incl - gs;
@@ -270,7 +284,9 @@ __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
                     const uint32_t last = cnt - 1u;
                     carry_glob = __builtin_amdgcn_readlane(g_incl, last);
                     const uint32_t nidx = base + cnt;
-                    const uint32_t nf_start = (nidx / p.chunks_per_frame) * p.chunks_per_frame;
+                    uint32_t ncf;
+                    (void)div_magic(nidx, p.chunks_per_frame, p.magic_cpf, ncf);
+                    const uint32_t nf_start = nidx - ncf;
                     // frame of the next record starts at nf_start: its prefix is known if nf_start <= nidx
                     if (nf_start == nidx) frame_start_glob = carry_glob;
                     else if (nf_start >= base) frame_start_glob = __builtin_amdgcn_readlane(g_excl, nf_start - base);
@@ -369,18 +385,19 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
     ChunkRef k;
     k.c = c;
     k.valid = c < p.n_chunks;
-    k.f = k.valid ? c / p.chunks_per_frame : 0u;
-    k.cf = k.valid ? c - k.f * p.chunks_per_frame : 0u;
+    uint32_t cf = 0;
+    k.f = k.valid ? div_magic(c, p.chunks_per_frame, p.magic_cpf, cf) : 0u;
+    k.cf = k.valid ? cf : 0u;
     if (p.lanes_per_row == 0u) {            // plain: 1024 consecutive tiles
         k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
         k.hasA = k.valid && k.t0 < p.T;
         k.hasB = k.valid && k.t0 + 1u < p.T;
-        k.ty = k.t0 / p.w;
-        k.tx = k.t0 - k.ty * p.w;
+        k.ty = div_magic(k.t0, p.w, p.magic_w, k.tx);
     } else {                                // the lane's pair: tile row = pair / lanes_per_row
         const uint32_t pair = k.cf * (kEncChunkTiles / 2u) + (uint32_t)tidw;
-        k.ty = pair / p.lanes_per_row;
-        k.tx = 2u * (pair - k.ty * p.lanes_per_row);
+        uint32_t j;
+        k.ty = div_magic(pair, p.lanes_per_row, p.magic_lpr, j);
+        k.tx = 2u * j;
         k.t0 = k.ty * p.w + k.tx;
         k.hasA = k.valid && k.ty < p.h;
         k.hasB = k.hasA && k.tx + 1u < p.w;
@@ -413,14 +430,17 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
         // at the result.  With a conditional issue the compiler cannot know how many loads are in
         // flight and makes the statistics of the CURRENT chunk wait for these as well.
         const uint32_t ty = k.hasA ? k.ty : 0u, tx = k.hasA ? k.tx : 0u;
-        uint32_t x0 = 8u * tx;
-        if (IN_MODE == kInRaw) x0 = x0 + 16u <= (uint32_t)p.W ? x0 : (uint32_t)p.W - 16u;   // stay inside the row
-        const uint8_t *base = img + (size_t)x0;
+        const uint32_t x0 = 8u * tx;
+        // kInRaw: the 16 bytes of a row's last lane run into the next image row -- harmless, those bytes are replaced by
+        // the constant padding (load_fixup_generic) -- except in the last image row of the batch, where they would pass
+        // the end of the caller's buffer: there, and only there, the fetch is moved left to END at the row's last pixel
+        const bool at_end = IN_MODE == kInRaw && k.f == p.last_frame && x0 + 16u > (uint32_t)p.W;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int yy = 8 * (int)ty + r;
             yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
-            const uint8_t *src = base + (size_t)yy * (size_t)p.W;
+            const uint32_t xr = at_end && yy == p.H - 1 ? (uint32_t)p.W - 16u : x0;
+            const uint8_t *src = img + (size_t)yy * (size_t)p.W + xr;
             u32x4_t q;
             if (IN_MODE == kInFast) {
                 q = DBDE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(src))
@@ -440,34 +460,52 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
 }
 
 // Second half of the kInRaw load (see load_chunk): applied to the registers of `k` when they are used.  Only the
-// last lane(s) of an image row have anything to do, so the work sits behind a wave-uniform test.
+// last lane(s) of an image row have anything to do, so the work sits behind wave-uniform tests:
+//   * the constant padding of a tile row's last tile(s): the last valid pixel repeated (dbde_util.cpp:116-128) --
+//     branch-free on the two dwords of a tile row, per-lane masks (valid columns rm == 8 changes nothing);
+//   * in the last image row of the batch the fetch had been moved left (load_chunk): shifted back first.
 template <int IN_MODE>
 __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                                    uint32_t (&vb)[16]) {
     if (IN_MODE != kInRaw) return;
     const uint32_t x0 = 8u * k.tx, W = (uint32_t)p.W;
-    const uint32_t sh = k.hasA && x0 + 16u > W ? x0 + 16u - W : 0u;           // bytes the fetch was moved left
-    const uint32_t rmA = !k.hasA ? 0u : (W - x0 < 8u ? W - x0 : 8u);          // valid columns of the two tiles
-    const uint32_t rmB = !k.hasB ? 0u : (W - x0 - 8u < 8u ? W - x0 - 8u : 8u);
-    if (__all((int)(!k.hasA || (rmA == 8u && rmB == 8u)))) return;
+    const uint32_t rmA = !k.hasA ? 8u : (W - x0 < 8u ? W - x0 : 8u);          // valid columns of the two tiles
+    const uint32_t rmB = !k.hasB ? 8u : (W - x0 - 8u < 8u ? W - x0 - 8u : 8u);
+    const bool at_end = k.hasA && k.f == p.last_frame && x0 + 16u > W;
+    if (__any((int)at_end)) {   // (once per launch, in the workgroup that holds the batch's last tile row)
+        const uint32_t sh = x0 + 16u - W;            // bytes the fetch was moved left: 1..15
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int yy = 8 * (int)k.ty + r;
+            yy = yy < p.H ? yy : p.H - 1;
+            if (at_end && yy == p.H - 1) {
+                uint64_t lo = ((uint64_t)va[2 * r + 1] << 32) | va[2 * r], hi = ((uint64_t)vb[2 * r + 1] << 32) | vb[2 * r];
+                if (sh >= 8u) { lo = hi >> (8u * (sh - 8u)); hi = 0; }
+                else { lo = (lo >> (8u * sh)) | (hi << (64u - 8u * sh)); hi >>= 8u * sh; }
+                va[2 * r] = (uint32_t)lo; va[2 * r + 1] = (uint32_t)(lo >> 32);
+                vb[2 * r] = (uint32_t)hi; vb[2 * r + 1] = (uint32_t)(hi >> 32);
+            }
+        }
+    }
+    if (__all((int)(rmA == 8u && rmB == 8u))) return;
+    auto masks = [](uint32_t rm, uint32_t &m0, uint32_t &m1, uint32_t &sh, bool &from_hi) {
+        m0 = rm >= 4u ? 0xFFFFFFFFu : (1u << (8u * rm)) - 1u;                                   // valid bytes of the low dword
+        m1 = rm <= 4u ? 0u : (rm >= 8u ? 0xFFFFFFFFu : (1u << (8u * (rm - 4u))) - 1u);          // ... of the high dword
+        from_hi = rm > 4u;                                                                      // where the last valid pixel is
+        sh = 8u * ((rm - 1u) & 3u);
+    };
+    uint32_t a0, a1, ash, b0, b1, bsh;
+    bool ahi, bhi;
+    masks(rmA, a0, a1, ash, ahi);
+    masks(rmB, b0, b1, bsh, bhi);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        uint64_t lo = ((uint64_t)va[2 * r + 1] << 32) | va[2 * r], hi = ((uint64_t)vb[2 * r + 1] << 32) | vb[2 * r];
-        if (sh >= 8u) { lo = hi >> (8u * (sh - 8u)); hi = 0; }
-        else if (sh != 0u) { lo = (lo >> (8u * sh)) | (hi << (64u - 8u * sh)); hi >>= 8u * sh; }
-        // constant padding to the right: the last valid pixel repeated (dbde_util.cpp:116-128)
-        if (rmA < 8u && rmA != 0u) {
-            lo &= ~0ull >> (64u - 8u * rmA);
-            lo |= (((lo >> (8u * (rmA - 1u))) & 0xFFull) * 0x0101010101010101ull) << (8u * rmA);
-        }
-        if (rmB < 8u && rmB != 0u) {
-            hi &= ~0ull >> (64u - 8u * rmB);
-            hi |= (((hi >> (8u * (rmB - 1u))) & 0xFFull) * 0x0101010101010101ull) << (8u * rmB);
-        }
-        if (rmA == 0u) lo = 0;
-        if (rmB == 0u) hi = 0;
-        va[2 * r] = (uint32_t)lo; va[2 * r + 1] = (uint32_t)(lo >> 32);
-        vb[2 * r] = (uint32_t)hi; vb[2 * r + 1] = (uint32_t)(hi >> 32);
+        const uint32_t fa = (((ahi ? va[2 * r + 1] : va[2 * r]) >> ash) & 0xFFu) * 0x01010101u;
+        const uint32_t fb = (((bhi ? vb[2 * r + 1] : vb[2 * r]) >> bsh) & 0xFFu) * 0x01010101u;
+        va[2 * r] = (va[2 * r] & a0) | (fa & ~a0);
+        va[2 * r + 1] = (va[2 * r + 1] & a1) | (fa & ~a1);
+        vb[2 * r] = (vb[2 * r] & b0) | (fb & ~b0);
+        vb[2 * r + 1] = (vb[2 * r + 1] & b1) | (fb & ~b1);
     }
 }
 
@@ -947,239 +985,98 @@ hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_ou
 }
 
 // ---------------------------------------------------------------------------------------
-// ENCODE, any geometry, one slot per frame: frame-sequential workgroups, pixels staged by LDS-DMA
+// ENCODE, one slot per frame: a workgroup per frame, no cross-workgroup prefix
 // ---------------------------------------------------------------------------------------
-// Widths that are not multiples of 16 (BASELINE configs[3], 1921x1081: every image row starts at a different byte
-// alignment) cost the kernels above twice: a lane's 16 bytes per row are an UNALIGNED global load (-14 % and 7 % more
-// bytes fetched: every row end's cache line is touched twice), and about half of the waves hold a row end and run the
-// edge fix-up.  And whatever the geometry, their chunk offsets come from a scan across workgroups: a chunk's payload
-// waits in LDS (64 KB per 1024 tiles) for a record round trip.
-//
-// When every frame has its own slot, a frame's bytes depend on nothing outside the frame (dbde_util.cpp:137-180 walks
-// one frame with one cursor).  So here a workgroup owns WHOLE FRAMES (b, b + G, b + 2G, ...) and walks a frame's chunks
-// in order: the in-frame prefix is a running sum in a register -- no records, no scanner, no polling, no assumption
-// about co-residency -- and the payload of a chunk leaves in the step that packed it.  What LDS that frees goes to the
-// pixels: each wave fetches the image rows of ITS 64 tiles (one tile per lane, 512 consecutive tiles per chunk) with
-// LDS-DMA (global_load_lds_dwordx4) as ALIGNED 16-byte blocks -- a wave's tiles lie in at most two tile rows, i.e. per
-// image row r in at most two byte ranges ("strips" A and B, <= 36 blocks together) -- and every lane then reads its
-// 8 bytes per row from the wave-private LDS image at whatever byte offset they landed (ds_read_b64 takes any
-// address).  No unaligned global access, nothing fetched twice by one wave, and the right edge is a mask on the one
-// lane that holds it (constant padding, dbde_util.cpp:116-132); bottom padding is a row index clamp.
-//
-// Pipeline per wave (stage and payload image are wave-private; ONE workgroup barrier per step, for the wave totals):
-//     pixels(k) in registers  ->  statistics, scan, [barrier], pack into the payload image
-//     s_waitcnt vmcnt(0)       : DMA(k+1) has landed (it was the youngest vector-memory operation: exact, no counting)
-//     pixels(k+1) -> registers (16 VGPRs: one tile)
-//     stores of chunk k (depth / minimum bytes, payload 16 B per lane), THEN DMA(k+2) into the stage just read
-// so the DMA of a chunk is in flight during the statistics and the packing of the chunk before it, and a wait never
-// has younger stores in front of the loads it is for.  (Vector loads and stores do not retire in order with respect
-// to each other on this part -- tests/test_kernel_listing.py -- which rules out a counted wait across stores.)
-// A block of 16 aligned bytes never crosses a page, and every block requested holds at least one byte of the image:
-// nothing unmapped is touched; bytes of a block that lie outside the image are never looked at.
-constexpr int kRowsWaves = 8;
-constexpr int kRowsThreads = 64 * kRowsWaves;
-constexpr uint32_t kRowsChunkTiles = 64 * kRowsWaves;        // one tile per lane
-constexpr uint32_t kRowsPitch = 36u * 16u;                   // LDS bytes per image row of a wave's stage (see RowsWave)
-constexpr uint32_t kRowsStageBytes = 8u * kRowsPitch;
-constexpr uint32_t kRowsPayWords = 64u * 8u + 64u;           // 64 tiles x 8 qwords + a trash qword per lane
+// In the kernels above a chunk's stores wait for every earlier chunk of the launch to be reduced, and the chunks in
+// front of it are being worked on by OTHER workgroups at that very moment: wave 0 of every workgroup spends 44-57 % of
+// its time waiting for the scanner's answer (-DDBDE_DIAG: 4 polls per wait, 5 % answered at the first), the other
+// waves wait for wave 0 at the barrier, and the whole launch moves at the pace of its slowest workgroup per round.
+// The dependency is real only where frames are concatenated.  When every frame has its own slot, a frame's bytes
+// depend on nothing outside the frame (dbde_util.cpp:137-180 walks one frame with one cursor): here ONE workgroup
+// walks ONE frame's chunks in order and the in-frame prefix is a running sum in a register.  No records, no scanner,
+// no polling, no atomics, no workspace, no co-residency to prove -- and the payload of a chunk leaves in the step that
+// packed it (the payload image is only the transposition buffer, not a parking place).  Same input modes, same
+// register double buffer for the pixels (loads of the next chunk in flight during the statistics of this one), same
+// one barrier per step (the wave totals) as encode_kernel; the hardware deals frames to workgroup slots as they free.
+template <int IN_MODE, bool ALIGNED_OUT>
+__global__ __launch_bounds__(kEncThreads, 4) void encode_frame_kernel(EncParams p) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kEncWaves][kWaveWords + 64];
+    __shared__ uint32_t s_tot[2][kEncWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t f = blockIdx.x, cpf = p.chunks_per_frame;
+    uint64_t *pay = s_pay[wave];
+    uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
+    ChunkRef cur = chunk_ref(p, f * cpf, tid);
+    load_chunk<IN_MODE>(p, cur, r0a, r0b);
+    ChunkRef nxt = chunk_ref(p, cpf > 1u ? f * cpf + 1u : 0xFFFFFFFFu, tid);
+    uint32_t inf = 0;   // payload words of the frame in front of cur
 
-struct RowsShared {
-    uint8_t stage[kRowsWaves][kRowsStageBytes];
-    uint64_t pay[kRowsWaves][kRowsPayWords];
-    uint32_t tot[2][kRowsWaves];
-};
-
-// The tiles of one wave in one chunk.  Everything is wave-uniform.
-struct RowsWave {
-    uint32_t t_first, n;         // first tile (stream order), tiles held (0..64)
-    uint32_t tyA, txA, nA, nB;   // strip A: tile row tyA, columns [txA, txA + nA); strip B: tile row tyA + 1, columns [0, nB)
-    uint32_t slotB;              // first 16-byte slot of strip B in a stage row: (8 nA + 30) / 16 >= blocks of strip A
-};
-__device__ __forceinline__ RowsWave rows_wave(const EncParams &p, uint32_t cf, uint32_t wave) {
-    RowsWave v;
-    v.t_first = cf * kRowsChunkTiles + 64u * wave;
-    v.n = v.t_first >= p.T ? 0u : (p.T - v.t_first < 64u ? p.T - v.t_first : 64u);
-    v.tyA = v.t_first / p.w;
-    v.txA = v.t_first - v.tyA * p.w;
-    v.nA = p.w - v.txA < v.n ? p.w - v.txA : v.n;   // (w >= 64: the rest, if any, fits the next tile row)
-    v.nB = v.n - v.nA;
-    v.slotB = (8u * v.nA + 30u) >> 4;
-    return v;
-}
-// Strip geometry of image row y = 8 * ty + r: first byte `g`, length, first aligned block, blocks.
-struct RowsStrip { const uint8_t *a0; uint32_t s, nb; };
-__device__ __forceinline__ RowsStrip rows_strip(const uint8_t *img, uint32_t W, uint32_t y, uint32_t x_first, uint32_t n_tiles) {
-    const uint8_t *g = img + (size_t)y * W + x_first;
-    const uint32_t len = W - x_first < 8u * n_tiles ? W - x_first : 8u * n_tiles;
-    RowsStrip t;
-    t.s = (uint32_t)(reinterpret_cast<uintptr_t>(g) & 15u);
-    t.a0 = g - t.s;
-    t.nb = (t.s + len + 15u) >> 4;
-    return t;
-}
-__device__ __forceinline__ void rows_issue(const EncParams &p, const RowsWave &v, uint32_t f, uint8_t *stage, int lane) {
-    const uint8_t *img = p.images + (size_t)f * p.frame_pixels;
-    const uint32_t W = (uint32_t)p.W, H = (uint32_t)p.H;
-#pragma unroll
-    for (uint32_t r = 0; r < 8u; r++) {
-        const uint32_t yA = 8u * v.tyA + r, yB = yA + 8u;
-        if (v.nA != 0u && yA < H) {
-            const RowsStrip t = rows_strip(img, W, yA, 8u * v.txA, v.nA);
-            if ((uint32_t)lane < t.nb)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(t.a0 + 16u * (uint32_t)lane),
-                                                 (__attribute__((address_space(3))) void *)(stage + r * kRowsPitch), 16, 0, DBDE_NT ? 2 : 0);
-        }
-        if (v.nB != 0u && yB < H) {
-            const RowsStrip t = rows_strip(img, W, yB, 0u, v.nB);
-            if ((uint32_t)lane < t.nb)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(t.a0 + 16u * (uint32_t)lane),
-                                                 (__attribute__((address_space(3))) void *)(stage + r * kRowsPitch + 16u * v.slotB), 16, 0, DBDE_NT ? 2 : 0);
-        }
-    }
-}
-// The lane's tile out of the wave's stage: 8 bytes per row at any byte address, constant padding at the two edges.
-__device__ __forceinline__ void rows_read(const EncParams &p, const RowsWave &v, uint32_t f, const uint8_t *stage, int lane,
-                                          uint32_t (&px)[16]) {
-    const uint8_t *img = p.images + (size_t)f * p.frame_pixels;
-    const uint32_t W = (uint32_t)p.W, H = (uint32_t)p.H;
-    const bool inA = (uint32_t)lane < v.nA;
-    const uint32_t col = inA ? (uint32_t)lane : (uint32_t)lane - v.nA;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)stage;
-    const uint32_t lane_off = lds0 + 8u * col + (inA ? 0u : 16u * v.slotB);
-    // rows >= H repeat the last image row (dbde_util.cpp:129-132): a clamp of the row index, per strip
-    const uint32_t rmaxA = H - 1u - 8u * v.tyA < 7u ? H - 1u - 8u * v.tyA : 7u;
-    const uint32_t rmaxB = v.nB == 0u ? 0u : (H - 9u - 8u * v.tyA < 7u ? H - 9u - 8u * v.tyA : 7u);
-    uint64_t q[8];
-#pragma unroll
-    for (uint32_t r = 0; r < 8u; r++) {
-        const uint32_t rA = r < rmaxA ? r : rmaxA, rB = r < rmaxB ? r : rmaxB;
-        const uint32_t offA = rA * kRowsPitch + (uint32_t)(reinterpret_cast<uintptr_t>(img + (size_t)(8u * v.tyA + rA) * W + 8u * v.txA) & 15u);
-        uint32_t off = offA;
-        if (v.nB != 0u) {   // wave-uniform
-            const uint32_t offB = rB * kRowsPitch + (uint32_t)(reinterpret_cast<uintptr_t>(img + (size_t)(8u * v.tyA + 8u + rB) * W) & 15u);
-            off = inA ? offA : offB;
-        }
-        const uint32_t a = lane_off + off;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(q[r]) : "v"(a) : "memory");
-    }
-    // (the compiler does not know these are LDS reads: the wait carries the registers so that no use can move above it)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
-    // right edge: the last tile of a tile row keeps its W % 8 valid columns and repeats the last one (dbde_util.cpp:116-128)
-    const uint32_t rm = W & 7u;
-    const uint32_t tx = inA ? v.txA + col : col;
-    const bool part = rm != 0u && (uint32_t)lane < v.n && tx == p.w - 1u;
-    if (__any((int)part)) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint64_t x = q[r] & (~0ull >> (64u - 8u * (rm ? rm : 8u)));
-            x |= (((x >> (8u * ((rm ? rm : 8u) - 1u))) & 0xFFull) * 0x0101010101010101ull) << (8u * (rm & 7u));
-            q[r] = part ? x : q[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) { px[2 * r] = (uint32_t)q[r]; px[2 * r + 1] = (uint32_t)(q[r] >> 32); }
-}
-
-__global__ __launch_bounds__(kRowsThreads, 4) void encode_rows_kernel(EncParams p) {
-    __shared__ __attribute__((aligned(16))) RowsShared sh;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6);
-    const uint32_t G = gridDim.x, cpf = p.chunks_per_frame, NF = p.n_chunks;   // n_chunks carries the frame count here
-    uint8_t *stage = sh.stage[wave];
-    uint64_t *pay = sh.pay[wave];
-    const uint64_t meta = 32ull + 2ull * p.T;
-
-    // (frame, chunk) sequence of this workgroup: every chunk of frames b, b + G, ...
-    uint32_t f = blockIdx.x, cf = 0;                                      // cur: pixels in registers
-    uint32_t nf = cpf > 1u ? f : f + G, ncf = cpf > 1u ? 1u : 0u;         // nxt: DMA in flight
-    RowsWave cur = rows_wave(p, cf, wave);
-    uint32_t px[16], nx[16];
-    if (f < NF) rows_issue(p, cur, f, stage, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (f < NF) rows_read(p, cur, f, stage, lane, px);
-    RowsWave nxt = rows_wave(p, ncf, wave);
-    if (nf < NF) rows_issue(p, nxt, nf, stage, lane);
-
-    uint32_t inf = 0, par = 0;     // payload words of the frame in front of this chunk
-    while (f < NF) {
+    auto step = [&](const uint32_t par, uint32_t (&ca)[16], uint32_t (&cb)[16], uint32_t (&na)[16],
+                    uint32_t (&nb)[16]) __attribute__((always_inline)) -> void {
+        load_chunk<IN_MODE>(p, nxt, na, nb);          // (a step past the frame's end loads dummies: static load count)
         // ---- statistics of cur (dbde_util.cpp:30-68), offsets inside the wave ----
-        const bool has = (uint32_t)lane < cur.n;
-        uint32_t mn, mx;
-        tile_minmax(px, mn, mx);
-        const uint32_t d = has ? depth_of_range(mx - mn) : 0u;
-        const uint32_t incl = wave_scan_incl(d);
+        uint32_t mnA, mxA, mnB, mxB;
+        load_fixup_generic<IN_MODE>(p, cur, ca, cb);
+        tile_minmax(ca, mnA, mxA);
+        tile_minmax(cb, mnB, mxB);
+        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
+        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
+        const uint32_t incl = wave_scan_incl(dA + dB);
         const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
-        if (lane == 0) sh.tot[par][wave] = wtot;
+        if (lane == 0) s_tot[par][wave] = wtot;
         __syncthreads();   // the one workgroup barrier of a step
         uint32_t wbase = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < kRowsWaves; k++) {
-            const uint32_t tk = sh.tot[par][k];
-            wbase += (uint32_t)k < wave ? tk : 0u;
+        for (int k = 0; k < kEncWaves; k++) {
+            const uint32_t tk = s_tot[par][k];
+            wbase += k < wave ? tk : 0u;
             total += tk;
         }
-        // ---- pack into the wave's payload image ----
-        const bool all8 = __builtin_amdgcn_readfirstlane(__all((int)(d == 8u || !has)));
+        // ---- pack into the wave's payload image, store from it ----
+        const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
         if (wtot != 0u) {
-            const uint32_t off = incl - d;
-            if (all8) { if (has) pack_tile_d8(px, mn, pay, off); }
-            else pack_tile(px, mn, d, pay, off, 64u * 8u + (uint32_t)lane);
-        }
-        // ---- DMA(nxt) has landed: its pixels to registers ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (nf < NF) rows_read(p, nxt, nf, stage, lane, nx);
-        // ---- stores of cur: depth / minimum bytes, the wave's contiguous payload range, frame fields ----
-        uint8_t *fb = p.out + (uint64_t)f * p.slot_stride;
-        if (has) {
-            fb[24u + cur.t_first + (uint32_t)lane] = (uint8_t)d;
-            fb[28u + p.T + cur.t_first + (uint32_t)lane] = (uint8_t)mn;
-        }
-        {
-            uint8_t *dst = fb + meta + 8ull * ((uint64_t)inf + wbase);
-            const uint32_t q0 = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);   // 1: dst is 8 mod 16
-            const uint32_t lead = q0 < wtot ? q0 : wtot;
-            if (lead && lane == 0) *reinterpret_cast<uint64_t *>(dst) = pay[0];
-            const uint32_t rest = wtot - lead, npairs = rest >> 1;
-            for (uint32_t i = (uint32_t)lane; i < npairs; i += 64u) {
-                const uint32_t q = lead + 2u * i;
-                const uint64_t lo = pay[all8 ? swzq8(q) : q], hi = pay[all8 ? swzq8(q + 1u) : q + 1u];
-                u32x4_t o;
-                o[0] = (uint32_t)lo; o[1] = (uint32_t)(lo >> 32); o[2] = (uint32_t)hi; o[3] = (uint32_t)(hi >> 32);
-                if (DBDE_NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(dst + 8ull * q));
-                else *reinterpret_cast<u32x4_t *>(dst + 8ull * q) = o;
-            }
-            if ((rest & 1u) && lane == 63) {
-                const uint32_t q = wtot - 1u;
-                *reinterpret_cast<uint64_t *>(dst + 8ull * q) = pay[all8 ? swzq8(q) : q];
+            const uint32_t offA = incl - (dA + dB), offB = offA + dA;
+            if (all8) {
+                if (cur.hasA) pack_tile_d8(ca, mnA, pay, offA);
+                if (cur.hasB) pack_tile_d8(cb, mnB, pay, offB);
+            } else {
+                pack_tile(ca, mnA, dA, pay, offA, kWaveWords + (uint32_t)lane);
+                pack_tile(cb, mnB, dB, pay, offB, kWaveWords + (uint32_t)lane);
             }
         }
-        if (tid == 64 * (kRowsWaves - 1) && (cf == 0u || cf == cpf - 1u)) write_frame_fields<true>(p, f, cf, inf + total, 0u);
-        // ---- the stage has been read: DMA of the chunk after nxt (youngest vector-memory operation of the step) ----
-        uint32_t nnf = nf, nncf = ncf + 1u;
-        if (nncf == cpf) { nnf = nf + G; nncf = 0u; }
-        const RowsWave nn = rows_wave(p, nncf, wave);
-        if (nf < NF && nnf < NF) rows_issue(p, nn, nnf, stage, lane);
-        // ---- rotate ----
-        inf = cf == cpf - 1u ? 0u : inf + total;
-#pragma unroll
-        for (int i = 0; i < 16; i++) px[i] = nx[i];
-        f = nf; cf = ncf; cur = nxt;
-        nf = nnf; ncf = nncf; nxt = nn;
-        par ^= 1u;
-    }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (cur.valid) {
+            store_wave_part<ALIGNED_OUT>(p, cur, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, inf, pay, lane,
+                                         all8 || DBDE_ENC_SWZ_ALL);
+            if (tid == 64 * (kEncWaves - 1) && (cur.cf == 0u || cur.cf == cpf - 1u))
+                write_frame_fields<ALIGNED_OUT>(p, cur.f, cur.cf, inf + total, 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        inf += total;
+        cur = nxt;
+        nxt = chunk_ref(p, nxt.valid && nxt.cf + 1u < cpf ? nxt.c + 1u : 0xFFFFFFFFu, tid);
+    };
+    do {   // ONE exit, behind step 1 (see encode_kernel: an exit between the steps costs a vmcnt(0) per step)
+        step(0u, r0a, r0b, r1a, r1b);
+        step(1u, r1a, r1b, r0a, r0b);
+    } while (cur.valid);
 }
 
-hipError_t launch_encode_rows(const EncParams &p, uint32_t n_frames, uint32_t grid_blocks, hipStream_t s) {
-    EncParams q = p;
-    q.n_chunks = n_frames;
-    q.chunks_per_frame = (p.T + kRowsChunkTiles - 1u) / kRowsChunkTiles;
-    hipLaunchKernelGGL(encode_rows_kernel, dim3(n_frames < grid_blocks ? n_frames : grid_blocks), dim3(kRowsThreads), 0, s, q);
-    return hipGetLastError();
+template <int IN_MODE>
+static void launch_encode_frame_mode(const EncParams &p, bool aligned_out, dim3 grid, hipStream_t s) {
+    if (aligned_out) hipLaunchKernelGGL((encode_frame_kernel<IN_MODE, true>), grid, dim3(kEncThreads), 0, s, p);
+    else hipLaunchKernelGGL((encode_frame_kernel<IN_MODE, false>), grid, dim3(kEncThreads), 0, s, p);
 }
-int encode_rows_blocks_per_cu() {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, encode_rows_kernel, kRowsThreads, 0) != hipSuccess || n < 1) n = 1;
-    return n;
+hipError_t launch_encode_frame(const EncParams &p, uint32_t n_frames, bool fast_in, bool aligned_out, hipStream_t s) {
+    const dim3 grid(n_frames);
+    switch (in_mode_of(p, fast_in)) {
+        case kInFast: launch_encode_frame_mode<kInFast>(p, aligned_out, grid, s); break;
+        case kInRaw: launch_encode_frame_mode<kInRaw>(p, aligned_out, grid, s); break;
+        default: launch_encode_frame_mode<kInBytes>(p, aligned_out, grid, s); break;
+    }
+    return hipGetLastError();
 }
 
 // Resident workgroups per CU of the encoder (occupancy query; LDS- and VGPR-bound).

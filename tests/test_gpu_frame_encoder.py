@@ -1,9 +1,10 @@
-"""GPU: the frame-sequential encoder (encode_rows_kernel, csrc/dbde_kernels.hip) -- widths that are not multiples of
-16, one slot per frame: a workgroup owns whole frames, pixels arrive by LDS-DMA as aligned blocks and are read back at
-their byte offset.  The C-ABI takes it by itself when there are enough frames to deal out; here it is FORCED for any
-frame count ($DBDE_HIP_EXPERIMENT bit 1) and every frame is compared byte for byte with the oracle: strips that
-straddle two tile rows, partial right-edge tiles (dbde_util.cpp:116-128), bottom padding (:129-132), the last chunk of
-a frame with idle waves, several frames per workgroup, explicit indices / elapsed_ns."""
+"""GPU: the per-frame encoder (encode_frame_kernel, csrc/dbde_kernels.hip) -- one slot per frame: a workgroup walks ONE
+frame's chunks in order, the in-frame prefix is a running sum, nothing is shared between workgroups.  The C-ABI takes it
+by itself when there are enough frames to fill the device; here it is FORCED for any frame count
+($DBDE_HIP_EXPERIMENT bit 1) and every frame is compared byte for byte with the oracle, in all three input modes:
+aligned widths, widths that are not multiples of 16 (partial right-edge tiles, dbde_util.cpp:116-128; bottom padding,
+:129-132; the fetch moved left in the batch's last image row), images narrower than two tiles; frames of one chunk and
+of many; byte-granular output (T % 4 != 0); explicit indices / elapsed_ns."""
 import hashlib
 import os
 
@@ -44,9 +45,10 @@ def _encode_slots(codec, imgs, W, H, n, first_index=0, **kw):
 
 
 @pytest.mark.parametrize("W,H,n", [(513, 17, 3), (520, 9, 2), (1001, 33, 5), (1025, 64, 2), (2047, 8, 3), (4095, 24, 2),
-                                   (1921, 1081, 2), (8200, 9, 2), (777, 777, 1), (515, 1, 4)])
+                                   (1921, 1081, 2), (8200, 9, 2), (777, 777, 1), (515, 1, 4), (4096, 3072, 2), (2048, 2048, 3),
+                                   (1920, 1080, 2), (10, 10, 5), (15, 40, 3), (16, 16, 4), (33, 31, 7), (1, 1, 3), (200, 123, 6)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
-def test_rows_encoder_matches_oracle(rows_codec, oracle, W, H, n, mode):
+def test_frame_encoder_matches_oracle(rows_codec, oracle, W, H, n, mode):
     import torch
     codec = rows_codec
     imgs = codec.synth_frames(mode, SEED, 100, n, W, H)
@@ -64,9 +66,8 @@ def test_rows_encoder_matches_oracle(rows_codec, oracle, W, H, n, mode):
     assert torch.equal(back, imgs)
 
 
-def test_rows_encoder_many_frames_per_workgroup(rows_codec, oracle):
-    """More frames than resident workgroups: every workgroup walks several frames (f, f + G, ...), with explicit frame
-    numbers and elapsed_ns (trap T1: F64 on the wire)."""
+def test_frame_encoder_many_frames(rows_codec, oracle):
+    """More frames than resident workgroup slots, explicit frame numbers and elapsed_ns (trap T1: F64 on the wire)."""
     import torch
     codec = rows_codec
     W, H, n = 513, 17, 1300
@@ -88,9 +89,9 @@ def test_rows_encoder_many_frames_per_workgroup(rows_codec, oracle):
 
 
 @pytest.mark.parametrize("mode", ["noise8", "mixed"])
-def test_rows_encoder_default_selection_config4(dv, golden, mode):
+def test_frame_encoder_default_selection_config4(dv, golden, mode):
     """BASELINE configs[3] as bench.py runs it (slots, 512 frames = one full round of workgroups): the library picks
-    the frame-sequential encoder by itself; frames 0 and 3 against the SHA-256 of the reference's own output."""
+    the per-frame encoder by itself; frames 0 and 3 against the SHA-256 of the reference's own output."""
     import torch
     manifest, _ = golden
     codec = dv.Codec(0)

@@ -369,7 +369,12 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     const uintptr_t ib = reinterpret_cast<uintptr_t>(d_images);
     int img_mode = 2;
     if (W % 128 == 0 && g.pixels % 128 == 0 && (ib & 127u) == 0) img_mode = 0;
-    else if (g.w <= kChunkTiles && W >= 16 && (kChunkTiles / g.w) * g.w * 10u >= kChunkTiles * 9u) img_mode = 1;
+    else if (g.w <= kChunkTiles && W >= 16 && (kChunkTiles / g.w) * g.w * 10u >= kChunkTiles * 9u) {
+        // image rows that are not 8-byte aligned are staged tile-aligned at pitch 8 w + 16: that image must fit the
+        // workgroup's LDS (narrow frames have many rows per chunk and do not)
+        const bool a8 = W % 8 == 0 && (ib & 7u) == 0;
+        if (a8 || 8ull * (kChunkTiles / g.w) * (8ull * g.w + 16ull) <= 34048ull) img_mode = 1;
+    }
 #ifdef DBDE_FORCE_GENERIC
     img_mode = 2;
 #endif
@@ -445,6 +450,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.T = g.T;
     p.chunks_per_frame = dcpf;
     p.n_chunks = (uint32_t)n_chunks64;
+    p.magic_W = div_magic_of((uint32_t)W);
     p.geom = dg;
     span_begin(ctx, 2);
     HIP_TRY(ctx, launch_decode(p, img_mode, self_index, ctx->stream));

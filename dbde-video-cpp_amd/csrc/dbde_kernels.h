@@ -106,6 +106,7 @@ struct DecParams {
     int W, H;
     uint32_t w, h, T;
     uint32_t chunks_per_frame, n_chunks;
+    uint32_t magic_W;               // div_magic_of(W): byte offset in a chunk's range -> (image row, column), staged copy-out
     DecGeom geom;
 };
 

@@ -1519,27 +1519,6 @@ __device__ __forceinline__ void lds_store_bytes(uint8_t *s_px, uint32_t a, uint6
     if (n & 1u) s_px[a] = (uint8_t)v;
 }
 
-// Staging at addresses that are not 8-byte aligned (odd widths): 8-byte LDS stores at odd addresses took five times
-// the aligned time inside the decode kernel, so a tile row is shifted in registers onto 4-byte aligned words.  `sr`
-// = address & 3 is the same for every tile of an image row; a tile owns the aligned words d0 = its first 4 - sr bytes
-// behind the last sr bytes of its LEFT neighbour (`prev`: that tile's upper dword) and d1; its own last sr bytes
-// travel in the right neighbour's d0.  The first tile of an image row has no left neighbour (its d0 spoils the last
-// bytes of the image row before) and the last one is not staged this way at all (it may be partial, and nobody
-// carries its last bytes): a second pass rewrites the last bytes of every image row (stage_row_end).
-__device__ __forceinline__ void stage_row_a4(uint8_t *s_px, uint32_t a4, uint32_t sr, uint32_t lo, uint32_t hi, uint32_t prev) {
-    const uint32_t sh = 4u - sr;   // 1..3 bytes are shifted (v_alignbyte_b32 takes the count modulo 4: sr == 0 is spelled out)
-    uint32_t *q = reinterpret_cast<uint32_t *>(s_px + a4);   // 4-byte aligned: ds_write2_b32
-    q[0] = sr ? __builtin_amdgcn_alignbyte(lo, prev, sh) : lo;
-    q[1] = sr ? __builtin_amdgcn_alignbyte(hi, lo, sh) : hi;
-}
-// The last tile of an image row (n = 1..8 valid bytes at byte address a): the three bytes in front of it (its left
-// neighbour's, when it has one) and its own, byte by byte.
-__device__ __forceinline__ void stage_row_end(uint8_t *s_px, uint32_t a, uint32_t lo, uint32_t hi, uint32_t prev, bool has_prev, uint32_t n) {
-    if (has_prev) { s_px[a - 3u] = (uint8_t)(prev >> 8); s_px[a - 2u] = (uint8_t)(prev >> 16); s_px[a - 1u] = (uint8_t)(prev >> 24); }
-    if (n == 8u) { __builtin_memcpy(s_px + a, &lo, 4); __builtin_memcpy(s_px + a + 4u, &hi, 4); }
-    else lds_store_bytes(s_px, a, ((uint64_t)hi << 32) | lo, n);
-}
-
 // Write one (possibly partial) tile: only the valid region (dbde_util.cpp:281-289).
 __device__ __forceinline__ void store_tile_generic(uint8_t *img, int W, int H, uint32_t w, uint32_t t,
                                                    const uint32_t (&v)[16]) {
@@ -1806,7 +1785,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         return;
     }
 
-    // ---- kImgLinear: stage the pixels in LDS as they lie in the frame, leave as whole cache lines ----------
+    // ---- kImgLinear: stage the pixels in LDS, leave as whole cache lines of the chunk's byte range ----------
     const bool whole_rows = p.geom.pieces == 1u;
     const uint32_t ty0 = whole_rows ? t_begin / p.w : cf / p.geom.pieces;
     const uint32_t tx0 = whole_rows ? 0u : (cf - ty0 * p.geom.pieces) * kChunkTiles;
@@ -1815,98 +1794,49 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     const uint32_t tile_rows = whole_rows ? n_tiles / p.w : 1u;
     const uint32_t y_end = y0 + 8u * tile_rows < (uint32_t)p.H ? y0 + 8u * tile_rows : (uint32_t)p.H;
     const uint32_t x_valid = Wu - 8u * tx0 < 8u * wspan ? Wu - 8u * tx0 : 8u * wspan;   // valid bytes of one image row here
-    // whole-row form: ONE range, image rows at pitch W; piece form: a range per image row, LDS pitch 4224
     uint8_t *g_first = img + (size_t)y0 * (size_t)p.W + (size_t)(8u * tx0);
-    const uint32_t l_pitch = whole_rows ? Wu : 8u * kChunkTiles + 128u;
-    // LDS byte address of image row ry (relative to y0), column byte xb:
-    //   whole rows: g7 + ry * W + xb                 (one range: LDS and global agree mod 128 throughout)
-    //   pieces    : ((g7 + ry * W) & 127) + ry * l_pitch + xb   (each image row is its own range)
     // mod 128, not 16: a wave's 64 x 16 B must cover whole cache lines (a 4-lane group one 64-byte sector),
     // or the stores run at little more than half rate however well each lane is aligned (profiles/mempattern.hip)
     const uint32_t g7 = (uint32_t)(reinterpret_cast<uintptr_t>(g_first) & 127u);
     uint8_t *s_px = reinterpret_cast<uint8_t *>(s_in);
-    // Off 8-byte alignment (odd widths) the staging needs a re-alignment in registers: extra issue work that pays
-    // where the unpack was cheap -- workgroups whose tiles are all of depth 0 or 8: incompressible content, +16-19 %
-    // at 1921x1081 -- and costs 5 % where tiles are unpacked bit by bit, so such a workgroup stores tile by tile
-    // instead.  The vote rides on the barrier that hands the LDS over.  (8-byte aligned rows are always staged: on
-    // bit-packed content that equals tile-by-tile stores from plain chunks and beats them from these row chunks.)
+    // Two layouts of the staged image:
+    //   a8 (image rows 8-byte aligned: W % 8 == 0 and an 8-byte aligned frame): the chunk's byte range AS IT LIES in the
+    //      frame (whole rows: one range, rows at pitch W; pieces of a wider row: a range per image row, LDS pitch 4224),
+    //      LDS and global addresses equal mod 128: tile rows go in as aligned 8-byte stores, blocks come out as they are;
+    //   otherwise (odd widths, whole rows): tiles cannot be stored where the frame has them -- 8-byte LDS stores at odd
+    //      addresses took five times the aligned time in this kernel, and shifting them in registers is issue work that
+    //      only paid for incompressible content -- so the image is staged TILE-ALIGNED, image rows at pitch 8 w + 16
+    //      (every tile row an aligned ds_write_b64), and the re-alignment moves to the read side of the copy-out, where
+    //      it is free: block j of the range's aligned cover is the 16 bytes at (row, column) = divmod(offset, W), one
+    //      ds_read_b128 at whatever address that is (the LDS takes any).  A block that runs over the end of an image
+    //      row continues in the 16 bytes behind it, which the first two tiles of the NEXT image row have also written
+    //      there (2 of w lanes, 8 unaligned stores each).
     const bool a8 = ((g7 | Wu) & 7u) == 0u;
-    __shared__ uint32_t s_edge[G::kWaves][8];
-    __shared__ uint32_t s_cheap[G::kWaves];
-    if (!a8 && lane == 63) {   // a wave's first lane needs the upper dwords of the tile left of it, which live in the wave before
-#pragma unroll
-        for (int r = 0; r < 8; r++) s_edge[wave][r] = vb[2 * r + 1];
-    }
-    if (!a8) {   // (lanes without a tile count as depth 0: a chunk's last, partly filled wave must not decide)
-        const bool simple = __all((int)((dA == 0u || dA == 8u) && (dB == 0u || dB == 8u)));
-        if (lane == 0) s_cheap[wave] = simple ? 1u : 0u;
+    if (!a8 && !whole_rows) {   // (pieces of an odd-width row wider than 4096: not staged; dbde_capi.cpp does not send them here)
+        if (hasA) store_tile_generic(img, p.W, p.H, p.w, t0, va);
+        if (hasB) store_tile_generic(img, p.W, p.H, p.w, t0 + 1u, vb);
+        return;
     }
     __syncthreads();   // every wave has finished reading the payload image: the memory changes hands
-    if (!a8) {
-        uint32_t cheap = 1u;
-#pragma unroll
-        for (int q = 0; q < G::kWaves; q++) cheap &= s_cheap[q];
-        if (!__builtin_amdgcn_readfirstlane(cheap)) {
-            if (hasA) store_tile_generic(img, p.W, p.H, p.w, t0, va);
-            if (hasB) store_tile_generic(img, p.W, p.H, p.w, t0 + 1u, vb);
-            return;
-        }
-    }
-    if (!a8) {
-        __shared__ uint64_t s_trash[64];
-        const uint32_t iA = 2u * (uint32_t)tid;
-        const uint32_t rowA = iA / wspan, colA = iA - rowA * wspan;
-        const uint32_t rowB = colA + 1u == wspan ? rowA + 1u : rowA, colB = colA + 1u == wspan ? 0u : colA + 1u;
-        const uint32_t nA = 8u * colA + 8u <= x_valid ? 8u : x_valid - 8u * colA;
-        const uint32_t nB = 8u * colB + 8u <= x_valid ? 8u : x_valid - 8u * colB;
-        const uint32_t aA = whole_rows ? g7 + 8u * rowA * Wu + 8u * colA : 8u * colA;
-        const uint32_t aB = whole_rows ? g7 + 8u * rowB * Wu + 8u * colB : 8u * colB;
-        const bool endA = hasA && colA + 1u == wspan, endB = hasB && colB + 1u == wspan;
-        const bool stageA = hasA && !endA, stageB = hasB && !endB;
-        const uint32_t trash = (uint32_t)(reinterpret_cast<uint8_t *>(&s_trash[lane]) - s_px);
-        uint32_t prevA[8];
-        // pass 1, no branches: every tile but the last of an image row (rows below the image's last, in the bottom
-        // chunk, are staged too: they lie behind the range that leaves)
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t rt = whole_rows ? (uint32_t)r * Wu : ((g7 + (uint32_t)r * Wu) & 127u) + (uint32_t)r * l_pitch;
-            const uint32_t sr = (g7 + (uint32_t)r * Wu) & 3u;    // wave-uniform: tiles are 8 bytes apart, tile rows 8 * W
-            const uint32_t edge = wave > 0 ? s_edge[wave - 1][r] : 0u;
-            // left neighbour of tile A = tile B of the lane before (wave_shr:1; lane 0 keeps `edge`)
-            prevA[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)vb[2 * r + 1], 0x138, 0xF, 0xF, false);
-            stage_row_a4(s_px, stageA ? aA + rt - sr : trash, sr, va[2 * r], va[2 * r + 1], prevA[r]);
-            stage_row_a4(s_px, stageB ? aB + rt - sr : trash, sr, vb[2 * r], vb[2 * r + 1], va[2 * r + 1]);
-        }
-        __syncthreads();
-        // pass 2: the last bytes of every image row (after pass 1: the first tile of the next image row spoiled some)
-        if (endA) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t rt = whole_rows ? (uint32_t)r * Wu : ((g7 + (uint32_t)r * Wu) & 127u) + (uint32_t)r * l_pitch;
-                stage_row_end(s_px, aA + rt, va[2 * r], va[2 * r + 1], prevA[r], colA != 0u, nA);
-            }
-        }
-        if (endB) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t rt = whole_rows ? (uint32_t)r * Wu : ((g7 + (uint32_t)r * Wu) & 127u) + (uint32_t)r * l_pitch;
-                stage_row_end(s_px, aB + rt, vb[2 * r], vb[2 * r + 1], va[2 * r + 1], colB != 0u, nB);
-            }
-        }
-    } else {
-        const uint32_t iA = 2u * (uint32_t)tid;
-        const uint32_t rowA = iA / wspan, colA = iA - rowA * wspan;
-        const uint32_t rowB = colA + 1u == wspan ? rowA + 1u : rowA, colB = colA + 1u == wspan ? 0u : colA + 1u;
-        // bytes of the tile's rows that exist in the image (8, or W % 8 for the last tile of an image row)
-        const uint32_t nA = 8u * colA + 8u <= x_valid ? 8u : x_valid - 8u * colA;
-        const uint32_t nB = 8u * colB + 8u <= x_valid ? 8u : x_valid - 8u * colB;
+    const uint32_t iA = 2u * (uint32_t)tid;
+    const uint32_t rowA = iA / wspan, colA = iA - rowA * wspan;
+    const uint32_t rowB = colA + 1u == wspan ? rowA + 1u : rowA, colB = colA + 1u == wspan ? 0u : colA + 1u;
+    // bytes of the tile's rows that exist in the image (8, or W % 8 for the last tile of an image row)
+    const uint32_t nA = 8u * colA + 8u <= x_valid ? 8u : x_valid - 8u * colA;
+    const uint32_t nB = 8u * colB + 8u <= x_valid ? 8u : x_valid - 8u * colB;
+    const bool all_rows = y0 + 8u * tile_rows <= (uint32_t)p.H;
+    const bool plain = all_rows && __all((int)((!hasA || nA == 8u) && (!hasB || nB == 8u)));   // no edge in this wave
+    if (a8) {
+        const uint32_t l_pitch = 8u * kChunkTiles + 128u;
+        // LDS byte address of image row ry (relative to y0), column byte xb:
+        //   whole rows: g7 + ry * W + xb                 (one range: LDS and global agree mod 128 throughout)
+        //   pieces    : ((g7 + ry * W) & 127) + ry * l_pitch + xb   (each image row is its own range)
         const uint32_t aA = whole_rows ? g7 + 8u * rowA * Wu + 8u * colA : 8u * colA;   // the tile's row 0, less the row term
         const uint32_t aB = whole_rows ? g7 + 8u * rowB * Wu + 8u * colB : 8u * colB;
         auto row_term = [&](uint32_t r) -> uint32_t {   // wave-uniform
             return whole_rows ? r * Wu : ((g7 + r * Wu) & 127u) + r * l_pitch;
         };
-        const bool all_rows = y0 + 8u * tile_rows <= (uint32_t)p.H;
-        if (all_rows && __all((int)((!hasA || nA == 8u) && (!hasB || nB == 8u)))) {   // no edge in this wave: straight stores
+        if (plain) {
             if (hasA) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aA + row_term((uint32_t)r), va[2 * r], va[2 * r + 1]);
@@ -1929,28 +1859,120 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
                 }
             }
         }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm stores are invisible to the compiler's counters
-    __syncthreads();
-    const uint32_t n_ranges = whole_rows ? 1u : y_end - y0;
-    for (uint32_t s = 0; s < n_ranges; s++) {
-        uint8_t *g0 = g_first + (size_t)s * Wu;
-        const uint32_t bytes = whole_rows ? (y_end - y0) * Wu : x_valid;
-        const uint32_t head = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 127u);
-        uint8_t *a0 = g0 - head;                                             // cache-line aligned
-        const uint8_t *l0 = s_px + (whole_rows ? 0u : s * l_pitch);          // LDS byte of global byte a0
-        const uint32_t n_blocks = (head + bytes + 15u) >> 4;
-        for (uint32_t j = (uint32_t)tid; j < n_blocks; j += (uint32_t)G::kThreads) {
-            if (16u * j + 16u <= head || 16u * j >= head + bytes) continue;   // (blocks of the first line before the range)
-            if (16u * j >= head && 16u * j + 16u <= head + bytes) {
-                const u32x4_t q = *reinterpret_cast<const u32x4_t *>(l0 + 16u * j);
-                if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(a0 + 16ull * j));
-                else *reinterpret_cast<u32x4_t *>(a0 + 16ull * j) = q;
-            } else {       // first / last block of the range: only the bytes that belong to it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm stores are invisible to the compiler's counters
+        __syncthreads();
+        const uint32_t n_ranges = whole_rows ? 1u : y_end - y0;
+        for (uint32_t s = 0; s < n_ranges; s++) {
+            uint8_t *g0 = g_first + (size_t)s * Wu;
+            const uint32_t bytes = whole_rows ? (y_end - y0) * Wu : x_valid;
+            const uint32_t head = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 127u);
+            uint8_t *a0 = g0 - head;                                             // cache-line aligned
+            const uint8_t *l0 = s_px + (whole_rows ? 0u : s * l_pitch);          // LDS byte of global byte a0
+            const uint32_t n_blocks = (head + bytes + 15u) >> 4;
+            for (uint32_t j = (uint32_t)tid; j < n_blocks; j += (uint32_t)G::kThreads) {
+                if (16u * j + 16u <= head || 16u * j >= head + bytes) continue;   // (blocks of the first line before the range)
+                if (16u * j >= head && 16u * j + 16u <= head + bytes) {
+                    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(l0 + 16u * j);
+                    if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(a0 + 16ull * j));
+                    else *reinterpret_cast<u32x4_t *>(a0 + 16ull * j) = q;
+                } else {       // first / last block of the range: only the bytes that belong to it
 #pragma unroll
-                for (uint32_t b = 0; b < 16u; b++) {
-                    const uint32_t o = 16u * j + b;
-                    if (o >= head && o < head + bytes) a0[o] = l0[o];
+                    for (uint32_t b = 0; b < 16u; b++) {
+                        const uint32_t o = 16u * j + b;
+                        if (o >= head && o < head + bytes) a0[o] = l0[o];
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- odd widths (whole rows; dbde_capi.cpp sends nothing else here): tile-aligned image, shifted copy-out ----
+    // Pass 1, no branch but "has a tile": EVERY tile row goes in as one aligned 8-byte store -- the partial last tile of
+    // an image row too (what it writes behind column W lies in the 16 bytes pass 2 rewrites), rows below the image too
+    // (they lie behind the range that leaves).
+    const uint32_t P = 8u * wspan + 16u;
+    const uint32_t aA = 8u * rowA * P + 8u * colA, aB = 8u * rowB * P + 8u * colB;
+    if (hasA) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aA + (uint32_t)r * P, va[2 * r], va[2 * r + 1]);
+    }
+    if (hasB) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aB + (uint32_t)r * P, vb[2 * r], vb[2 * r + 1]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // Pass 2: the first 16 bytes of every image row once more, behind the end of the image row before it (W >= 16:
+    // columns 0 and 1 are whole tiles; the chunk's first image row has no row before it in this chunk).
+    if (hasA && colA <= 1u) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t ry = 8u * rowA + (uint32_t)r;
+            if (ry != 0u) lds_store_u64_any(s_px, (ry - 1u) * P + Wu + 8u * colA, va[2 * r], va[2 * r + 1]);
+        }
+    }
+    if (hasB && colB <= 1u) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t ry = 8u * rowB + (uint32_t)r;
+            if (ry != 0u) lds_store_u64_any(s_px, (ry - 1u) * P + Wu + 8u * colB, vb[2 * r], vb[2 * r + 1]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const uint32_t bytes = (y_end - y0) * Wu;
+        uint8_t *a0 = g_first - g7;                                              // cache-line aligned
+        const uint32_t n_blocks = (g7 + bytes + 15u) >> 4;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)s_px;
+        // A block's 16 bytes start at any LDS byte address.  An under-aligned ds_read_b128 is legal but took 2-3 times the
+        // aligned time in this kernel (0.17 of 1.48 ms), so a block is five 4-byte aligned dwords (ds_read2_b32 x2 +
+        // ds_read_b32) and four v_alignbyte_b32 by the address' low two bits.  Four blocks per thread in flight, one wait.
+        // The first and the last block of the range are partial: their bytes (1..15, read from the first valid one
+        // on) leave as one store per set bit of the count.
+        const uint32_t last_n = (g7 + bytes) & 15u;                    // valid bytes of the last block (0: it is whole)
+        for (uint32_t j0 = (uint32_t)tid; j0 < n_blocks; j0 += 4u * (uint32_t)G::kThreads) {
+            uint64_t d01[4], d23[4];
+            uint32_t d4[4], a[4];
+            bool live[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t j = j0 + k * (uint32_t)G::kThreads;
+                live[k] = j < n_blocks && 16u * j + 16u > g7;          // holds at least one byte of the range
+                const uint32_t o = live[k] && 16u * j > g7 ? 16u * j - g7 : 0u;   // range offset of the first byte looked at
+                uint32_t col;
+                const uint32_t row = div_magic(o, Wu, p.magic_W, col);
+                a[k] = lds0 + row * P + col;
+                const uint32_t a4 = a[k] & ~3u;
+                asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16"
+                             : "=&v"(d01[k]), "=&v"(d23[k]), "=&v"(d4[k]) : "v"(a4) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d01[0]), "+v"(d23[0]), "+v"(d4[0]), "+v"(d01[1]), "+v"(d23[1]), "+v"(d4[1]),
+                         "+v"(d01[2]), "+v"(d23[2]), "+v"(d4[2]), "+v"(d01[3]), "+v"(d23[3]), "+v"(d4[3]) :: "memory");
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t j = j0 + k * (uint32_t)G::kThreads;
+                const uint32_t w0 = (uint32_t)d01[k], w1 = (uint32_t)(d01[k] >> 32), w2 = (uint32_t)d23[k], w3 = (uint32_t)(d23[k] >> 32);
+                u32x4_t q;
+                q[0] = __builtin_amdgcn_alignbyte(w1, w0, a[k]);
+                q[1] = __builtin_amdgcn_alignbyte(w2, w1, a[k]);
+                q[2] = __builtin_amdgcn_alignbyte(w3, w2, a[k]);
+                q[3] = __builtin_amdgcn_alignbyte(d4[k], w3, a[k]);
+                if (!live[k]) continue;
+                const bool first = 16u * j < g7, last = 16u * j + 16u > g7 + bytes;
+                if (!first && !last) {
+                    if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(a0 + 16ull * j));
+                    else *reinterpret_cast<u32x4_t *>(a0 + 16ull * j) = q;
+                } else {
+                    // q holds the range's bytes from the block's first valid one: n of them go to dst (any alignment)
+                    uint8_t *dst = first ? g_first : a0 + 16ull * j;
+                    uint32_t n = first ? 16u - (g7 & 15u) : last_n;
+                    if (first && last) n = bytes;                       // (a range shorter than one block)
+                    uint64_t lo = ((uint64_t)q[1] << 32) | q[0], hi = ((uint64_t)q[3] << 32) | q[2];
+                    if (n & 8u) { store_u64_any(dst, lo); dst += 8; lo = hi; }
+                    if (n & 4u) { const uint32_t v = (uint32_t)lo; __builtin_memcpy(dst, &v, 4); dst += 4; lo >>= 32; }
+                    if (n & 2u) { const uint16_t v = (uint16_t)lo; __builtin_memcpy(dst, &v, 2); dst += 2; lo >>= 16; }
+                    if (n & 1u) *dst = (uint8_t)lo;
                 }
             }
         }

@@ -615,9 +615,20 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     p.fgsum = p.fsize + n;
     p.sticky = ctx->sticky;
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
+    if (!ctx->enc16_grid) ctx->enc16_grid = (uint32_t)(dbde16::encode16_blocks_per_cu() * ctx->n_cu);
+    // one slot per frame and enough frames to fill the device's workgroup slots (the last round of them 85 % full):
+    // a workgroup per frame, no prefix from anybody ($DBDE_HIP_EXPERIMENT bit 1 forces it, bit 2 keeps the records)
+    if (slot_stride != 0 && !(ctx->exp_flags & 4u)) {
+        const uint64_t G = ctx->enc16_grid, rounds = ((uint64_t)n_frames + G - 1) / G;
+        if ((ctx->exp_flags & 2u) || (uint64_t)n_frames * 100u >= rounds * G * 85u) {
+            span_begin(ctx, 0);
+            HIP_TRY(ctx, dbde16::launch_encode16_frames(p, n_frames, ctx->stream));
+            span_end(ctx);
+            return DBDE_HIP_OK;
+        }
+    }
     span_begin(ctx, 0);
     HIP_TRY(ctx, hipMemsetAsync(ctx->w16, 0, need, ctx->stream));
-    if (!ctx->enc16_grid) ctx->enc16_grid = (uint32_t)(dbde16::encode16_blocks_per_cu() * ctx->n_cu);
     p.force_tickets = (ctx->exp_flags & 1u) ? 1u : 0u;
     HIP_TRY(ctx, dbde16::launch_encode16(p, n_frames, ctx->enc16_grid, ctx->stream));
     span_end(ctx);

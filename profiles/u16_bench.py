@@ -6,6 +6,9 @@ sys.path.insert(0, ROOT)
 import dbde_video_cpp_amd as dv
 
 W, H, n = 4096, 3072, 128
+SLOTS = False
+if len(sys.argv) > 1 and sys.argv[1] == "frames":   # one slot per frame, as many frames as the device has workgroup slots x 2
+    W, H, n, SLOTS = 1024, 768, 2048, True
 codec = dv.Codec(0)
 g = torch.Generator(device="cuda").manual_seed(1)
 d = torch.randint(0, 17, (n, H // 8, W // 8), device="cuda", generator=g)
@@ -15,11 +18,13 @@ noise = torch.randint(0, 65536, (n, H, W), device="cuda", generator=g) & mask
 base = torch.randint(0, 32768, (n, H // 8, W // 8), device="cuda", generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
 imgs = torch.minimum(base, 65535 - mask).add_(noise).to(torch.int32).to(torch.int16).contiguous()   # two's complement bits = the U16 pixels
 del d, dd, mask, noise, base
-cap = n * int(codec.L.dbde16_hip_max_frame_bytes(W, H))
+maxf = int(codec.L.dbde16_hip_max_frame_bytes(W, H))
+slot = ((maxf + 255) // 256) * 256 if SLOTS else 0
+cap = (n - 1) * slot + maxf if SLOTS else n * maxf
 buf = torch.empty(32 + cap + 64, dtype=torch.uint8, device="cuda")
 out = torch.empty_like(imgs)
 for _ in range(2):
-    offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap)
+    offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap, slot_stride=slot)
     codec.decode_frames16(buf, 32, cap, offs, W, H, n, images=out)
 codec.sync()
 assert torch.equal(out, imgs)
@@ -28,7 +33,7 @@ codec.timing(True); codec.timing_read(reset=True)
 steps = 10
 t0 = time.perf_counter()
 for _ in range(steps):
-    offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap)
+    offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap, slot_stride=slot)
     codec.decode_frames16(buf, 32, cap, offs, W, H, n, images=out)
 codec.sync()
 dt = (time.perf_counter() - t0) / steps

@@ -46,8 +46,6 @@ struct DecParams16 {
 
 int encode16_blocks_per_cu();   // resident workgroups per CU of the persistent encoder (occupancy query)
 hipError_t launch_encode16(const Params16 &p, int n_frames, uint32_t resident_blocks, hipStream_t s);
-// One slot per frame (slot_stride != 0): a workgroup per frame, running prefix, no workspace (enc16_frame_kernel).
-hipError_t launch_encode16_frames(const Params16 &p, int n_frames, hipStream_t s);
 hipError_t launch_decode16(const DecParams16 &p, int n_frames, hipStream_t s);
 
 }  // namespace dbde16

@@ -335,73 +335,6 @@ __global__ __launch_bounds__(kChunkTiles16, DBDE16_WAVES) void enc16_kernel(Para
     }
 }
 
-// ---- encode, one slot per frame: a workgroup per frame ---------------------------------------------------------------
-// enc16_kernel pays one coherent round trip per 256-tile chunk for its prefix (6 of the 13 us of a chunk's life: the
-// chunks in front of it are being reduced by other workgroups at that very moment).  With a slot per frame a frame's
-// bytes depend on nothing outside the frame: ONE workgroup walks ONE frame's chunks in order, the prefix is a running
-// sum, nothing is published or polled (the 8-bit encode_frame_kernel's reasoning).  The next chunk's tile is loaded
-// before this one is packed (registers, not LDS, are the landing zone).  Worth it when the launch has about as many
-// frames as the device has workgroup slots (dbde_capi.cpp decides).
-__global__ __launch_bounds__(kChunkTiles16, DBDE16_WAVES) void enc16_frame_kernel(Params16 p) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kPayWords16 + 1];   // + the trash word
-    __shared__ uint32_t s_tot[2][kChunkTiles16 / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t f = blockIdx.x, cpf = p.chunks_per_frame;
-    const uint64_t meta = 32ull + 3ull * p.T;
-    uint8_t *fb = p.out + (uint64_t)f * p.slot_stride;
-    const uint16_t *img = p.images + (size_t)f * p.frame_pixels;
-    uint32_t inf = 0;
-    Tile16 k = tile_of(p, f * cpf, tid);
-    uint32_t v[32], nv[32];
-    load_tile16(img, p.W, p.H, k.ty, k.tx, v);
-    for (uint32_t cf = 0; cf < cpf; cf++) {
-        const Tile16 kn = tile_of(p, f * cpf + (cf + 1u < cpf ? cf + 1u : cf), tid);
-        load_tile16(img, p.W, p.H, kn.ty, kn.tx, nv);              // in flight during the statistics and the packing below
-        uint32_t mn, mx;
-        tile_minmax16(v, mn, mx);
-        const uint32_t d = k.has ? depth_of(mx - mn) : 0u;
-        const uint32_t incl = wave_scan_incl(d);
-        if (lane == 63u) s_tot[cf & 1u][wave] = incl;
-        __syncthreads();   // wave totals; also: the previous chunk's copy-out has finished reading the image
-        uint32_t wbase = 0, total = 0;
-        for (uint32_t q = 0; q < kChunkTiles16 / 64; q++) { wbase += q < wave ? s_tot[cf & 1u][q] : 0u; total += s_tot[cf & 1u][q]; }
-        pack_tile16(v, mn, d, s_pay, wbase + incl - d, 0u);
-        if (k.has) {   // metadata of this lane's tile
-            fb[24 + k.t] = (uint8_t)d;
-            uint8_t *m = fb + 28 + p.T + 2ull * k.t;
-            m[0] = (uint8_t)mn; m[1] = (uint8_t)(mn >> 8);
-        }
-        __syncthreads();   // the image is complete
-        uint8_t *dst = fb + meta + 8ull * inf;   // the chunk's contiguous payload
-        copy_out16(s_pay, dst, total < kPayWords16 ? total : kPayWords16, tid);
-        if (total > kPayWords16) {   // (nearly) every tile of depth 16: the words the image had no room for
-            __syncthreads();
-            pack_tile16(v, mn, d, s_pay, wbase + incl - d, kPayWords16);
-            __syncthreads();
-            copy_out16(s_pay, dst + 8ull * kPayWords16, total - kPayWords16, tid);
-        }
-        if (tid == 0) {
-            if (cf == 0u) {   // frame header and the first I32 fields (trap T1: elapsed travels as an F64; 0 here)
-                store_u32_bytes(fb, 2u);
-                store_u64_any(fb + 4, p.first_index + f);
-                store_u64_any(fb + 12, 0ull);
-                store_u32_bytes(fb + 20, p.T);
-                store_u32_bytes(fb + 24 + p.T, 2u * p.T);
-                if (p.frame_offsets) p.frame_offsets[f] = (uint64_t)f * p.slot_stride;
-            }
-            if (cf == cpf - 1u) {
-                const uint32_t words = inf + total;
-                store_u32_bytes(fb + 28 + 3ull * p.T, words);
-                if (p.frame_bytes) p.frame_bytes[f] = meta + 8ull * words;
-            }
-        }
-        inf += total;
-        k = kn;
-#pragma unroll
-        for (int i = 0; i < 32; i++) v[i] = nv[i];
-    }
-}
-
 // ---- decode ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kChunkTiles16 * 128 + 48];
@@ -526,11 +459,6 @@ int encode16_blocks_per_cu() {
 hipError_t launch_encode16(const Params16 &p, int n_frames, uint32_t resident_blocks, hipStream_t s) {
     const uint32_t n_chunks = (uint32_t)n_frames * p.chunks_per_frame;
     hipLaunchKernelGGL(enc16_kernel, dim3(n_chunks < resident_blocks ? n_chunks : resident_blocks), dim3(kChunkTiles16), 0, s, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_encode16_frames(const Params16 &p, int n_frames, hipStream_t s) {
-    hipLaunchKernelGGL(enc16_frame_kernel, dim3((uint32_t)n_frames), dim3(kChunkTiles16), 0, s, p);
     return hipGetLastError();
 }
 

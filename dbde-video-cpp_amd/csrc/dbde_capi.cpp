@@ -311,21 +311,6 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.flags = ctx->exp_flags;
     p.grid_blocks = ctx->enc_grid;
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
-    p.ctrl = nullptr;
-    p.state = nullptr;
-
-    // One slot per frame: frames are independent, a workgroup per frame needs no prefix from anybody (encode_frame_kernel).
-    // Taken when the frames fill the device's workgroup slots well: at least one round of them, the last round 85 % full
-    // ($DBDE_HIP_EXPERIMENT bit 1 forces it for any count -- tests; bit 2 keeps the scan-based kernels -- A/B).
-    if (slot_stride != 0 && !(ctx->exp_flags & 4u)) {
-        const uint64_t G = ctx->enc_grid, rounds = ((uint64_t)n_frames + G - 1) / G;
-        if ((ctx->exp_flags & 2u) || (uint64_t)n_frames * 100u >= rounds * G * 85u) {
-            span_begin(ctx, 0);
-            HIP_TRY(ctx, launch_encode_frame(p, (uint32_t)n_frames, fast_in, aligned_out, ctx->stream));
-            span_end(ctx);
-            return DBDE_HIP_OK;
-        }
-    }
 
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
     {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
@@ -616,17 +601,6 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     p.sticky = ctx->sticky;
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     if (!ctx->enc16_grid) ctx->enc16_grid = (uint32_t)(dbde16::encode16_blocks_per_cu() * ctx->n_cu);
-    // one slot per frame and enough frames to fill the device's workgroup slots (the last round of them 85 % full):
-    // a workgroup per frame, no prefix from anybody ($DBDE_HIP_EXPERIMENT bit 1 forces it, bit 2 keeps the records)
-    if (slot_stride != 0 && !(ctx->exp_flags & 4u)) {
-        const uint64_t G = ctx->enc16_grid, rounds = ((uint64_t)n_frames + G - 1) / G;
-        if ((ctx->exp_flags & 2u) || (uint64_t)n_frames * 100u >= rounds * G * 85u) {
-            span_begin(ctx, 0);
-            HIP_TRY(ctx, dbde16::launch_encode16_frames(p, n_frames, ctx->stream));
-            span_end(ctx);
-            return DBDE_HIP_OK;
-        }
-    }
     span_begin(ctx, 0);
     HIP_TRY(ctx, hipMemsetAsync(ctx->w16, 0, need, ctx->stream));
     p.force_tickets = (ctx->exp_flags & 1u) ? 1u : 0u;

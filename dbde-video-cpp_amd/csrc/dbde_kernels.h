@@ -138,10 +138,6 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
 // self-cleaning workspace (records and counters are zero on entry and on exit).
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
-// One slot per frame (slot_stride != 0): a workgroup per frame walks the frame's chunks in order, the in-frame prefix is
-// a running sum -- no workspace, no scanner, nothing shared between workgroups.  Worth it from about one frame per
-// resident workgroup slot (dbde_capi.cpp decides).
-hipError_t launch_encode_frame(const EncParams &p, uint32_t n_frames, bool fast_in, bool aligned_out, hipStream_t s);
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
 // self_index: no index kernel ran; every workgroup validates the frame and finds its offset itself (few frames)

@@ -22,6 +22,9 @@
 #ifndef DBDE_POLL
 #define DBDE_POLL 0   // where the encoder polls its mailbox (0 = round-1 order, A/B builds only)
 #endif
+#ifndef DBDE_LINE_ALIGNED_STORES
+#define DBDE_LINE_ALIGNED_STORES 1   // A/B switch: 0 = payload stores start at the wave's first 16-byte boundary
+#endif
 #ifndef DBDE_NT
 #define DBDE_NT 1   // non-temporal hint on the streamed-once traffic (pixels, payload, decoded images)
 #endif
@@ -591,8 +594,19 @@ __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkR
         if (lead && lane == 0) *reinterpret_cast<uint64_t *>(dst) = pay[0];
         const uint32_t rest = wtot - lead;
         const uint32_t npairs = rest >> 1;
+        // 16-byte pieces from here on.  The wave's range starts wherever the tiles in front of it ended: the pieces in
+        // front of the first 128-byte boundary (h of them, 0..7) leave with the LAST h lanes of a first, partial
+        // instruction, so that every other store instruction of the wave covers whole cache lines (a 1 KB wave store
+        // that straddles lines runs at little more than half the rate of an aligned one, profiles/mempattern.hip)
+#if DBDE_LINE_ALIGNED_STORES
+        const uint32_t h = (uint32_t)((128u - (uint32_t)(reinterpret_cast<uintptr_t>(dst + 8u * lead) & 127u)) & 127u) >> 4;
+        for (int base = h ? (int)h - 64 : 0; base < (int)npairs; base += 64) {
+            const int i = base + lane;
+            if (i < 0 || i >= (int)npairs) continue;
+#else
         for (uint32_t i = lane; i < npairs; i += 64u) {
-            const uint32_t q = lead + 2u * i;
+#endif
+            const uint32_t q = lead + 2u * (uint32_t)i;
             ulonglong2 v2;
             v2.x = pay[swz ? swzq8(q) : q];
             v2.y = pay[swz ? swzq8(q + 1u) : q + 1u];
@@ -980,101 +994,6 @@ hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_ou
         case kInRaw * 2 + 0: hipLaunchKernelGGL((encode_small_kernel<kInRaw, false>), grid, block, 0, s, p); break;
         case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInBytes, true>), grid, block, 0, s, p); break;
         default: hipLaunchKernelGGL((encode_small_kernel<kInBytes, false>), grid, block, 0, s, p); break;
-    }
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------
-// ENCODE, one slot per frame: a workgroup per frame, no cross-workgroup prefix
-// ---------------------------------------------------------------------------------------
-// In the kernels above a chunk's stores wait for every earlier chunk of the launch to be reduced, and the chunks in
-// front of it are being worked on by OTHER workgroups at that very moment: wave 0 of every workgroup spends 44-57 % of
-// its time waiting for the scanner's answer (-DDBDE_DIAG: 4 polls per wait, 5 % answered at the first), the other
-// waves wait for wave 0 at the barrier, and the whole launch moves at the pace of its slowest workgroup per round.
-// The dependency is real only where frames are concatenated.  When every frame has its own slot, a frame's bytes
-// depend on nothing outside the frame (dbde_util.cpp:137-180 walks one frame with one cursor): here ONE workgroup
-// walks ONE frame's chunks in order and the in-frame prefix is a running sum in a register.  No records, no scanner,
-// no polling, no atomics, no workspace, no co-residency to prove -- and the payload of a chunk leaves in the step that
-// packed it (the payload image is only the transposition buffer, not a parking place).  Same input modes, same
-// register double buffer for the pixels (loads of the next chunk in flight during the statistics of this one), same
-// one barrier per step (the wave totals) as encode_kernel; the hardware deals frames to workgroup slots as they free.
-template <int IN_MODE, bool ALIGNED_OUT>
-__global__ __launch_bounds__(kEncThreads, 4) void encode_frame_kernel(EncParams p) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_pay[kEncWaves][kWaveWords + 64];
-    __shared__ uint32_t s_tot[2][kEncWaves];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t f = blockIdx.x, cpf = p.chunks_per_frame;
-    uint64_t *pay = s_pay[wave];
-    uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-    ChunkRef cur = chunk_ref(p, f * cpf, tid);
-    load_chunk<IN_MODE>(p, cur, r0a, r0b);
-    ChunkRef nxt = chunk_ref(p, cpf > 1u ? f * cpf + 1u : 0xFFFFFFFFu, tid);
-    uint32_t inf = 0;   // payload words of the frame in front of cur
-
-    auto step = [&](const uint32_t par, uint32_t (&ca)[16], uint32_t (&cb)[16], uint32_t (&na)[16],
-                    uint32_t (&nb)[16]) __attribute__((always_inline)) -> void {
-        load_chunk<IN_MODE>(p, nxt, na, nb);          // (a step past the frame's end loads dummies: static load count)
-        // ---- statistics of cur (dbde_util.cpp:30-68), offsets inside the wave ----
-        uint32_t mnA, mxA, mnB, mxB;
-        load_fixup_generic<IN_MODE>(p, cur, ca, cb);
-        tile_minmax(ca, mnA, mxA);
-        tile_minmax(cb, mnB, mxB);
-        const uint32_t dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
-        const uint32_t dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
-        const uint32_t incl = wave_scan_incl(dA + dB);
-        const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
-        if (lane == 0) s_tot[par][wave] = wtot;
-        __syncthreads();   // the one workgroup barrier of a step
-        uint32_t wbase = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < kEncWaves; k++) {
-            const uint32_t tk = s_tot[par][k];
-            wbase += k < wave ? tk : 0u;
-            total += tk;
-        }
-        // ---- pack into the wave's payload image, store from it ----
-        const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
-        if (wtot != 0u) {
-            const uint32_t offA = incl - (dA + dB), offB = offA + dA;
-            if (all8) {
-                if (cur.hasA) pack_tile_d8(ca, mnA, pay, offA);
-                if (cur.hasB) pack_tile_d8(cb, mnB, pay, offB);
-            } else {
-                pack_tile(ca, mnA, dA, pay, offA, kWaveWords + (uint32_t)lane);
-                pack_tile(cb, mnB, dB, pay, offB, kWaveWords + (uint32_t)lane);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (cur.valid) {
-            store_wave_part<ALIGNED_OUT>(p, cur, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, inf, pay, lane,
-                                         all8 || DBDE_ENC_SWZ_ALL);
-            if (tid == 64 * (kEncWaves - 1) && (cur.cf == 0u || cur.cf == cpf - 1u))
-                write_frame_fields<ALIGNED_OUT>(p, cur.f, cur.cf, inf + total, 0u);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        inf += total;
-        cur = nxt;
-        nxt = chunk_ref(p, nxt.valid && nxt.cf + 1u < cpf ? nxt.c + 1u : 0xFFFFFFFFu, tid);
-    };
-    do {   // ONE exit, behind step 1 (see encode_kernel: an exit between the steps costs a vmcnt(0) per step)
-        step(0u, r0a, r0b, r1a, r1b);
-        step(1u, r1a, r1b, r0a, r0b);
-    } while (cur.valid);
-}
-
-template <int IN_MODE>
-static void launch_encode_frame_mode(const EncParams &p, bool aligned_out, dim3 grid, hipStream_t s) {
-    if (aligned_out) hipLaunchKernelGGL((encode_frame_kernel<IN_MODE, true>), grid, dim3(kEncThreads), 0, s, p);
-    else hipLaunchKernelGGL((encode_frame_kernel<IN_MODE, false>), grid, dim3(kEncThreads), 0, s, p);
-}
-hipError_t launch_encode_frame(const EncParams &p, uint32_t n_frames, bool fast_in, bool aligned_out, hipStream_t s) {
-    const dim3 grid(n_frames);
-    switch (in_mode_of(p, fast_in)) {
-        case kInFast: launch_encode_frame_mode<kInFast>(p, aligned_out, grid, s); break;
-        case kInRaw: launch_encode_frame_mode<kInRaw>(p, aligned_out, grid, s); break;
-        default: launch_encode_frame_mode<kInBytes>(p, aligned_out, grid, s); break;
     }
     return hipGetLastError();
 }

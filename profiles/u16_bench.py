@@ -7,7 +7,7 @@ import dbde_video_cpp_amd as dv
 
 W, H, n = 4096, 3072, 128
 SLOTS = False
-if len(sys.argv) > 1 and sys.argv[1] == "frames":   # one slot per frame, as many frames as the device has workgroup slots x 2
+if len(sys.argv) > 1 and sys.argv[1] == "frames":   # many small frames, one slot each
     W, H, n, SLOTS = 1024, 768, 2048, True
 codec = dv.Codec(0)
 g = torch.Generator(device="cuda").manual_seed(1)

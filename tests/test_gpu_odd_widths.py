@@ -1,10 +1,9 @@
-"""GPU: the per-frame encoder (encode_frame_kernel, csrc/dbde_kernels.hip) -- one slot per frame: a workgroup walks ONE
-frame's chunks in order, the in-frame prefix is a running sum, nothing is shared between workgroups.  The C-ABI takes it
-by itself when there are enough frames to fill the device; here it is FORCED for any frame count
-($DBDE_HIP_EXPERIMENT bit 1) and every frame is compared byte for byte with the oracle, in all three input modes:
-aligned widths, widths that are not multiples of 16 (partial right-edge tiles, dbde_util.cpp:116-128; bottom padding,
-:129-132; the fetch moved left in the batch's last image row), images narrower than two tiles; frames of one chunk and
-of many; byte-granular output (T % 4 != 0); explicit indices / elapsed_ns."""
+"""GPU: widths that are not multiples of 16, one slot per frame and concatenated -- the encoder's any-geometry input
+path (kInRaw: the 16 bytes of a row's last lane run into the next image row and are replaced by the constant padding,
+dbde_util.cpp:116-128; in the batch's LAST image row the fetch is moved left instead, so that nothing is read past the
+caller's buffer; bottom padding, :129-132) and the decoder's staged copy-out (tile-aligned LDS image, re-alignment on the
+read side).  Every frame byte for byte against the oracle, odd / even tile counts, one chunk and many, byte-granular
+output (T % 4 != 0), explicit indices / elapsed_ns; BASELINE configs[3] against the reference's own SHA-256."""
 import hashlib
 import os
 
@@ -23,11 +22,7 @@ def dv():
 
 @pytest.fixture(scope="module")
 def rows_codec(dv):
-    os.environ["DBDE_HIP_EXPERIMENT"] = "2"
-    try:
-        c = dv.Codec(0)
-    finally:
-        os.environ.pop("DBDE_HIP_EXPERIMENT", None)
+    c = dv.Codec(0)
     yield c
     c.close()
 
@@ -48,7 +43,7 @@ def _encode_slots(codec, imgs, W, H, n, first_index=0, **kw):
                                    (1921, 1081, 2), (8200, 9, 2), (777, 777, 1), (515, 1, 4), (4096, 3072, 2), (2048, 2048, 3),
                                    (1920, 1080, 2), (10, 10, 5), (15, 40, 3), (16, 16, 4), (33, 31, 7), (1, 1, 3), (200, 123, 6)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
-def test_frame_encoder_matches_oracle(rows_codec, oracle, W, H, n, mode):
+def test_slots_match_oracle(rows_codec, oracle, W, H, n, mode):
     import torch
     codec = rows_codec
     imgs = codec.synth_frames(mode, SEED, 100, n, W, H)
@@ -66,8 +61,8 @@ def test_frame_encoder_matches_oracle(rows_codec, oracle, W, H, n, mode):
     assert torch.equal(back, imgs)
 
 
-def test_frame_encoder_many_frames(rows_codec, oracle):
-    """More frames than resident workgroup slots, explicit frame numbers and elapsed_ns (trap T1: F64 on the wire)."""
+def test_many_small_odd_frames(rows_codec, oracle):
+    """More frames than resident workgroups, explicit frame numbers and elapsed_ns (trap T1: F64 on the wire)."""
     import torch
     codec = rows_codec
     W, H, n = 513, 17, 1300
@@ -89,9 +84,9 @@ def test_frame_encoder_many_frames(rows_codec, oracle):
 
 
 @pytest.mark.parametrize("mode", ["noise8", "mixed"])
-def test_frame_encoder_default_selection_config4(dv, golden, mode):
-    """BASELINE configs[3] as bench.py runs it (slots, 512 frames = one full round of workgroups): the library picks
-    the per-frame encoder by itself; frames 0 and 3 against the SHA-256 of the reference's own output."""
+def test_config4_against_reference_sha(dv, golden, mode):
+    """BASELINE configs[3] as bench.py runs it (slots): frames 0 and 3 against the SHA-256 of the reference's own output;
+    the last frame's last image row is where the encoder's fetch is moved left."""
     import torch
     manifest, _ = golden
     codec = dv.Codec(0)

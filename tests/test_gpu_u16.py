@@ -21,21 +21,6 @@ def codec():
     c.close()
 
 
-@pytest.fixture(scope="module")
-def codec_frames():
-    """A context that takes the per-frame encoder (enc16_frame_kernel) for every slot-layout call, whatever the frame
-    count ($DBDE_HIP_EXPERIMENT bit 1); concatenated calls still go through the record-based kernel."""
-    import os
-    import dbde_video_cpp_amd as dv
-    os.environ["DBDE_HIP_EXPERIMENT"] = "2"
-    try:
-        c = dv.Codec(0)
-    finally:
-        os.environ.pop("DBDE_HIP_EXPERIMENT", None)
-    yield c
-    c.close()
-
-
 def make_images(rng, n, W, H, kind):
     if kind == "full":
         img = rng.integers(0, 65536, size=(n, H, W))
@@ -53,10 +38,8 @@ def make_images(rng, n, W, H, kind):
 @pytest.mark.parametrize("W,H,n", [(8, 8, 1), (10, 10, 3), (64, 64, 4), (200, 123, 5), (1, 1, 2), (7, 300, 2),
                                    (1024, 40, 3), (4104, 16, 2), (33, 31, 7)])
 @pytest.mark.parametrize("kind", ["full", "mixed", "small"])
-@pytest.mark.parametrize("which", ["codec", "codec_frames"])
-def test_encode_matches_oracle_and_round_trips(request, o16, W, H, n, kind, which):
+def test_encode_matches_oracle_and_round_trips(codec, o16, W, H, n, kind):
     import torch
-    codec = request.getfixturevalue(which)
     rng = np.random.default_rng(W * 7 + H * 3 + n + len(kind))
     imgs_h = make_images(rng, n, W, H, kind)
     imgs = torch.from_numpy(imgs_h.view(np.int16)).cuda()
@@ -162,28 +145,3 @@ def test_malformed_frames_are_rejected(codec, o16):
     assert r[0] == (2, 4, 0, len(good)) and (back[0].cpu().numpy().view(np.uint16) == img).all()
     for k in (1, 2, 3):
         assert r[k][0] == 0xFFFFFFFF and r[k][3] == 20 and (back[k] == 0x5A5A).all()
-
-
-@pytest.mark.parametrize("kind", ["mixed", "full"])
-def test_per_frame_encoder_many_frames(codec, o16, kind):
-    """Enough frames, one slot each: the library takes the per-frame encoder by itself (1024 workgroup slots on an
-    MI355X; 1100 frames = two rounds, the second 7 % full: below the 85 % rule, so this count goes through the
-    record-based kernel, 2048 through the per-frame one) -- both must give the oracle's bytes."""
-    import torch
-    W, H = 256, 136
-    for n in (1100, 2048):
-        rng = np.random.default_rng(n)
-        imgs_h = make_images(rng, n, W, H, kind)
-        imgs = torch.from_numpy(imgs_h.view(np.int16)).cuda()
-        maxf = int(codec.L.dbde16_hip_max_frame_bytes(W, H))
-        slot = ((maxf + 255) // 256) * 256
-        cap = (n - 1) * slot + maxf
-        buf = torch.empty(32 + cap + 64, dtype=torch.uint8, device="cuda")
-        offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap, slot_stride=slot)
-        back, res = codec.decode_frames16(buf, 32, cap, offs, W, H, n)
-        codec.sync()
-        assert torch.equal(back, imgs), (kind, n)
-        o, s = offs.cpu().numpy(), sizes.cpu().numpy()
-        for f in (0, 1, n // 2, n - 1):
-            want = pack16(o16, imgs_h[f], f)
-            assert buf[32 + int(o[f]): 32 + int(o[f] + s[f])].cpu().numpy().tobytes() == want.tobytes(), (kind, n, f)

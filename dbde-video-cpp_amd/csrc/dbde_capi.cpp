@@ -377,6 +377,17 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     // couple of loads per thread: for a 4096x3072 frame (T = 196,608, 384 workgroups re-reading it) the same
     // idea took 38 us against 11 us for index + decode, measured.
     const bool self_index = g.T <= 8192u && n_chunks64 * (uint64_t)g.T <= (8ull << 20);
+    if (g.T <= 64u) {   // tiny frames (the tile-level entry points, thumbnails): several frames per wave, nothing else needed
+        DecParams tp;
+        memset(&tp, 0, sizeof tp);
+        tp.stream = d_stream; tp.frame_offsets = d_frame_offsets; tp.stream_bytes = stream_bytes;
+        tp.images = d_images; tp.results = d_results; tp.frame_pixels = g.pixels;
+        tp.W = W; tp.H = H; tp.w = g.w; tp.h = g.h; tp.T = g.T;
+        span_begin(ctx, 2);
+        HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
+        span_end(ctx);
+        return DBDE_HIP_OK;
+    }
     if (!self_index) {
         int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64 + (size_t)n_frames, sizeof(uint32_t));
         if (rc) return rc;

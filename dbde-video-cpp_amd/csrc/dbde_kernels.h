@@ -142,6 +142,9 @@ hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
 // self_index: no index kernel ran; every workgroup validates the frame and finds its offset itself (few frames)
 hipError_t launch_decode(const DecParams &p, int img_mode, bool self_index, hipStream_t s);
+// Frames of at most 64 tiles: one tile per lane, 64 / T frames per wave, validation and offsets by a segmented wave scan
+// (no index kernel, no workspace).
+hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t s);
 hipError_t launch_synth(int mode, uint64_t seed, uint64_t first_frame, int n_frames, int W, int H,
                         uint8_t *d_images, hipStream_t s);
 // Serial frame-to-frame hop over a concatenated stream (one wave); see dbde_hip_index_stream.

@@ -1898,6 +1898,86 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// DECODE, tiny frames (T <= 64 tiles: up to 64x64 pixels): one tile per lane, several frames per wave
+// ---------------------------------------------------------------------------------------
+// The reference's own randomized test decodes 1024 single-tile frames (dbde_util_test.cpp:66-96,366); thumbnails are the
+// same regime.  A workgroup per chunk leaves 511 of 512 tile slots empty there and the index kernel (a workgroup per
+// frame) costs more than the decode it serves (64x64 x 262,144 frames: index 2.6 ms, decode 1.1 ms, 0.18 of peak
+// together).  Here a lane owns ONE tile and a wave 64 / T whole frames: the frame's validation (dbde_util.cpp:295-303,
+// plus depth <= 8 and the readable extent) and the tile's word offset are a segmented wave scan over the depth bytes --
+// no index kernel, no LDS, no barrier -- and a tile row is the 8 bytes at byte r * d of the tile's payload, fetched
+// straight from the stream (rows of neighbouring lanes share cache lines).
+__global__ __launch_bounds__(256) void decode_tiny_kernel(DecParams p) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t T = p.T, fpw = 64u / T;                 // frames per wave
+    const uint32_t fl = lane / T, t = lane - fl * T;        // frame within the wave, tile within the frame
+    const uint32_t f = (blockIdx.x * 4u + wave) * fpw + fl;
+    const bool active = fl < fpw && f < p.n_chunks;          // (n_chunks carries the frame count here)
+    const uint64_t need = 32ull + 2ull * T;
+    const uint64_t foff = active ? p.frame_offsets[f] : 0ull;
+    const bool in_range = active && in_extent(foff, need, p.stream_bytes);
+    const uint8_t *fb = p.stream + foff;
+    uint32_t d = 0, mn = 0;
+    if (in_range) { d = fb[24u + t]; mn = fb[28u + T + t]; }
+    // depth sum and "a depth above 8" count of every frame in one scan: low 16 bits words (<= 64 * 255), high bits flags
+    const uint32_t item = in_range ? (d | (d > 8u ? 1u << 16 : 0u)) : 0u;
+    const uint32_t incl = wave_scan_incl(item);
+    const uint32_t first = fl * T;                            // the frame's first lane
+    const uint32_t base = (uint32_t)__shfl((int)(incl - item), (int)(first < 64u ? first : 0u), 64);
+    const uint32_t upto = (uint32_t)__shfl((int)incl, (int)(first + T - 1u < 64u ? first + T - 1u : 63u), 64);
+    const uint32_t total = (upto - base) & 0xFFFFu, n_bad = (upto - base) >> 16;
+    const uint32_t prefix = (incl - item - base) & 0xFFFFu;  // payload words of the frame in front of this tile
+    bool ok = in_range;
+    if (ok) {
+        const int32_t nb = (int32_t)load_u32_bytes(fb + 20), nm = (int32_t)load_u32_bytes(fb + 24 + T);
+        const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
+        ok = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && n_bad == 0u &&
+             in_extent(foff, need + 8ull * total, p.stream_bytes);
+    }
+    if (active && t == 0u && p.results) {   // the frame's result record: dbde_unpack_frame's return value
+        uint32_t field = 0;
+        uint64_t index = 0, elapsed = 0;
+        if (in_extent(foff, 20, p.stream_bytes)) {
+            field = load_u32_bytes(fb);
+            index = load_u64_bytes(fb + 4);
+            elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
+        }
+        FrameResultDev *r = reinterpret_cast<FrameResultDev *>(p.results) + f;
+        r->u64s = (field == 2u && ok) ? 2u : 0xFFFFFFFFu;   // dbde_util.cpp:335,342
+        r->pad_ = 0;
+        r->index = index;
+        r->elapsed_ns = elapsed;
+        r->consumed = ok ? need + 8ull * total : 20ull;
+    }
+    if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
+    const uint8_t *pay = fb + need + 8ull * prefix, *s_end = p.stream + p.stream_bytes;
+    const uint32_t mn4 = mn * 0x01010101u;
+    uint32_t v[16];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint64_t row = 0;
+        if (d != 0u) {
+            const uint8_t *q = pay + (uint32_t)r * d;
+            if (q + 8 <= s_end) row = load_u64_any(q);
+            else for (uint32_t b = 0; b < d; b++) row |= (uint64_t)q[b] << (8u * b);   // the stream's last bytes: nothing past the extent
+        }
+        uint32_t lo, hi;
+        expand_row(row, d, lo, hi);
+        v[2 * r] = add_bytes(lo, mn4);
+        v[2 * r + 1] = add_bytes(hi, mn4);
+    }
+    store_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
+}
+
+hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t s) {
+    DecParams q = p;
+    q.n_chunks = n_frames;
+    const uint32_t per_wg = 4u * (64u / p.T);
+    hipLaunchKernelGGL(decode_tiny_kernel, dim3((n_frames + per_wg - 1u) / per_wg), dim3(256), 0, s, q);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode(const DecParams &p, int img_mode, bool self_index, hipStream_t s) {
     dim3 grid(p.n_chunks), block(kChunkTiles / 2);
     switch (img_mode * 2 + (self_index ? 1 : 0)) {

@@ -41,15 +41,19 @@ def function_body(listing, mangled):
 
 
 def pixel_load_groups(lines):
-    """[(index of the last load, [vmcnt immediates up to the next barrier])] for every group of eight
-    non-temporal 16-byte loads (a step's pixel fetch; a few address instructions may sit between them)."""
+    """[(index of the first load, index of the last, [vmcnt immediates up to the next barrier, repeats dropped])] for
+    every group of non-temporal 16-byte loads (a step's pixel fetch; address arithmetic may sit between the loads, a
+    label, a branch or a vector-memory wait ends a group)."""
     idx = [i for i, ln in enumerate(lines)
            if ln.strip().startswith("global_load_dwordx4") and ln.strip().endswith("nt")]
     groups, cur = [], []
     for i in idx:
-        if cur and i - cur[-1] > 12:
-            groups.append(cur)
-            cur = []
+        if cur:
+            between = [ln.strip() for ln in lines[cur[-1] + 1:i]]
+            if i - cur[-1] > 40 or any(b.startswith((".LBB", "s_barrier", "s_cbranch", "s_branch")) or
+                                       re.match(r"s_waitcnt.*vmcnt", b) for b in between):
+                groups.append(cur)
+                cur = []
         cur.append(i)
     if cur:
         groups.append(cur)
@@ -62,20 +66,24 @@ def pixel_load_groups(lines):
             if t.startswith("s_barrier"):
                 break
             m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", t)
-            if m:
+            if m and (not waits or waits[-1] != int(m.group(1))):
                 waits.append(int(m.group(1)))
-        out.append((g[-1], waits))
+        out.append((g[0], g[-1], waits))
     return out
 
 
-@pytest.mark.parametrize("mangled", ["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE",
-                                     "_ZN4dbde13encode_kernelILi0ELb0EEEvNS_9EncParamsE"])
-def test_fast_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing, mangled):
+PERSISTENT = ["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0EEEvNS_9EncParamsE",
+              "_ZN4dbde13encode_kernelILi1ELb1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi1ELb0EEEvNS_9EncParamsE"]
+
+
+@pytest.mark.parametrize("mangled", PERSISTENT)
+def test_persistent_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing, mangled):
+    """Aligned widths (encode_kernel<0,*>) and any geometry (<1,*>: BASELINE configs[3]'s kernel)."""
     lines = function_body(listing, mangled)
     groups = pixel_load_groups(lines)
-    steady = [(i, w) for i, w in groups if w]   # the prologue's group meets a barrier first (drained behind it)
+    steady = [(a, b, w) for a, b, w in groups if w]   # the prologue's group meets a barrier first (drained behind it)
     assert len(steady) == 2, f"expected the two unrolled pipeline steps, found {len(steady)} ({groups})"
-    for last, w in steady:
+    for first_load, last, w in steady:
         assert w[:8] == [15, 14, 13, 12, 11, 10, 9, 8], (
             f"pixel waits are {w[:8]}: looser than 15..8 means younger stores are being counted on to retire in "
             f"order; tighter means the prefetch no longer overlaps the statistics")
@@ -91,6 +99,35 @@ def test_fast_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing, mangl
             f"vector-memory wait in front of the prefetch: {[b for b in block if b.startswith('s_waitcnt')]}"
 
 
+@pytest.mark.parametrize("mangled", ["_ZN4dbde19encode_small_kernelILi0ELb1EEEvNS_9EncParamsE",
+                                     "_ZN4dbde19encode_small_kernelILi0ELb0EEEvNS_9EncParamsE",
+                                     "_ZN4dbde19encode_small_kernelILi1ELb1EEEvNS_9EncParamsE",
+                                     "_ZN4dbde19encode_small_kernelILi1ELb0EEEvNS_9EncParamsE"])
+def test_small_encoder_waits_for_its_own_loads_only(listing, mangled):
+    """One workgroup per chunk, no prefetch: the eight pixel loads are consumed in order with vmcnt(7) ... vmcnt(0) --
+    nothing older is outstanding, nothing younger is counted on."""
+    groups = pixel_load_groups(function_body(listing, mangled))
+    assert len(groups) == 1, groups
+    assert groups[0][2][:8] == [7, 6, 5, 4, 3, 2, 1, 0], groups[0][2]
+
+
+def test_dbde16_encoder_waits(listing):
+    """enc16_kernel: a chunk's eight tile-row loads are waited for before any of the chunk's stores is issued -- the
+    first vector-memory wait behind them never allows more than the seven younger loads to be outstanding."""
+    text = open(os.path.join(CSRC, "dbde16_kernels.s")).read()
+    lines = function_body(text, "_ZN6dbde1612enc16_kernelENS_8Params16E")
+    idx = [i for i, ln in enumerate(lines) if ln.strip().startswith("global_load_dwordx4")]
+    assert len(idx) >= 8
+    first_group = idx[:8]
+    assert not any(ln.strip().startswith(("global_store", "buffer_store")) for ln in lines[first_group[0]:first_group[-1]])
+    for ln in lines[first_group[-1] + 1:]:
+        m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", ln.strip())
+        if m:
+            assert int(m.group(1)) <= 7, ln
+            break
+        assert not ln.strip().startswith(("global_store", "buffer_store")), "a store before the chunk's loads were waited for"
+
+
 def test_no_scratch_and_expected_occupancy(listing):
     """The hot kernels must not spill and must keep the residency the design assumes: encoder <= 128 VGPRs
     (2 workgroups of 8 waves per CU); decoder: LDS (<= 40 KB) allows 4 workgroups = 4 waves per SIMD, registers must
@@ -101,9 +138,11 @@ def test_no_scratch_and_expected_occupancy(listing):
         get = lambda k: re.search(r"\.?%s:\s+(\S+)" % k, entry).group(1)
         meta[get("name")] = {"vgpr": int(get("vgpr_count")), "scratch": int(get("private_segment_fixed_size")),
                              "lds": int(get("group_segment_fixed_size"))}
-    enc = meta["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE"]
-    assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, enc
-    dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi")]
+    for name in PERSISTENT + ["_ZN4dbde19encode_small_kernelILi0ELb1EEEvNS_9EncParamsE",
+                              "_ZN4dbde19encode_small_kernelILi1ELb1EEEvNS_9EncParamsE"]:
+        enc = meta[name]
+        assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, (name, enc)
+    dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi") or k.startswith("_ZN4dbde18decode_tiny_kernel")]
     assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 96 and d["lds"] <= 40 * 1024 for d in dec), dec
 
 

@@ -631,6 +631,13 @@ template <int IN_MODE, bool ALIGNED_OUT>
 __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     __shared__ __attribute__((aligned(16))) EncShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DBDE_DIAG
+    if (tid == 0) {   // when the launch's workgroups start (wall clock, 10 ns): earliest as a max of the complement
+        const unsigned long long t = wall_clock64();
+        atomicMax(&p.diag[11], ~t);
+        atomicMax(&p.diag[12], t);
+    }
+#endif
 
     // The first workgroup to get here becomes the scanner: one of its waves runs the in-order
     // scan, the others retire.  Being first to run, it is a running workgroup by construction.
@@ -677,6 +684,12 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     }
     __syncthreads();
     const bool static_mode = __builtin_amdgcn_readfirstlane(sh.boot[1]) == 1u;
+    // Static strides leave the launch's tail to chance: workgroups do not run at the same speed (the first leaves 30-40 us
+    // before the last on a 1-4 ms launch).  The last kTailRounds rounds of chunk ids -- everything from s_static on, the
+    // same boundary for every workgroup -- are therefore drawn as tickets (ctrl[0]) even in static mode: ids stay dense, a
+    // ticket belongs to a running workgroup, and a fast workgroup simply draws more of them.
+    constexpr uint32_t kTailRounds = 3;
+    const uint32_t s_static = p.n_chunks > (kTailRounds + 1u) * G ? (p.n_chunks / G - kTailRounds) * G : 0xFFFFFFFFu;
     ChunkRef nxt = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[0]), tid);
     ChunkRef prev = chunk_ref(p, 0xFFFFFFFFu, tid);
     uint64_t *pay = sh.pay[wave];
@@ -724,7 +737,11 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
                     if (!ok) atomicOr(p.sticky, 1u);
                 }
                 uint32_t tnew = 0xFFFFFFFFu;   // id of the chunk after nxt
-                if (nxt.valid) tnew = static_mode ? nxt.c + G : atomicAdd(&p.ctrl[2], 1u);
+                if (nxt.valid) {
+                    if (!static_mode) tnew = atomicAdd(&p.ctrl[2], 1u);
+                    else if (nxt.c + G < s_static) tnew = nxt.c + G;
+                    else tnew = s_static + atomicAdd(&p.ctrl[0], 1u);
+                }
                 sh.lb[par][0] = inf;
                 sh.lb[par][1] = glob;
                 sh.lb[par][2] = ok;
@@ -857,6 +874,9 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         atomicAdd(&p.diag[8], 1ull);
         atomicAdd(&p.diag[9], dg_npoll);
         atomicAdd(&p.diag[10], dg_first);
+        const unsigned long long t = wall_clock64();   // ... and when they leave
+        atomicMax(&p.diag[13], ~t);
+        atomicMax(&p.diag[14], t);
     }
 #endif
 }

@@ -92,6 +92,12 @@ int main(int argc, char **argv) {
     double ms[4] = {0, 0, 0, 0};
     uint64_t n[4] = {0, 0, 0, 0};
     dbde_hip_timing_read(c, ms, n, 1);
+    if (getenv("ABBENCH_DIAG")) {   // counters of the warm-up launches: read and dropped
+        using fn_diag = int (*)(ctx *, uint64_t *);
+        fn_diag dr = (fn_diag)dlsym(h, "dbde_hip_diag_read");
+        uint64_t junk[16];
+        if (dr) dr(c, junk);
+    }
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < steps; i++) if (step()) return 1;
     if (dbde_hip_sync(c)) { fprintf(stderr, "sync: %s\n", dbde_hip_last_error(c)); return 1; }
@@ -108,6 +114,11 @@ int main(int argc, char **argv) {
                     "scanner per launch: %.0f rounds, %.1f %% idle, %.1f records/round, %.0f cyc\n", tag, content,
                     d[2] / wg, d[0] / wg, 100.0 * d[0] / d[2], d[1] / wg, (double)d[9] / (d[1] ? d[1] : 1), 100.0 * d[10] / (d[1] ? d[1] : 1), d[7] / wg, 100.0 * d[7] / d[2],
                     (double)d[3] / steps, 100.0 * d[4] / (d[3] ? d[3] : 1), (double)d[6] / (d[3] ? d[3] : 1), (double)d[5] / steps);
+            if (d[11] && steps == 1) {   // one timed launch: when its workgroups started and left (10 ns wall clock)
+                const double t0 = (double)(~d[11]);
+                fprintf(stderr, "diag[%s]: workgroups start within %.1f us; first leaves at %.1f us, last at %.1f us after the first start\n", tag,
+                        ((double)d[12] - t0) / 100.0, ((double)(~d[13]) - t0) / 100.0, ((double)d[14] - t0) / 100.0);
+            }
         }
     }
     const double alg = (double)px * B + packed;

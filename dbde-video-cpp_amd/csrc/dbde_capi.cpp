@@ -59,6 +59,9 @@ struct dbde_hip_ctx {
     size_t frame_ok_n = 0;
     uint32_t *idx_ctr = nullptr;     // [2 * n]: arrival counters, then flags, of the split index kernel (kept zero)
     size_t idx_ctr_n = 0;
+    unsigned long long *fuse_rec = nullptr;   // records of the fused index + decode launch (epoch-tagged, never cleared)
+    size_t fuse_rec_n = 0;
+    uint32_t fuse_epoch = 0;
     // sticky failure word (device) + scratch
     uint32_t *sticky = nullptr;
     uint64_t *scratch64 = nullptr;   // small device scratch: [0..3]
@@ -207,6 +210,7 @@ void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     if (ctx->chunk_off) (void)hipFree(ctx->chunk_off);
     if (ctx->frame_ok) (void)hipFree(ctx->frame_ok);
     if (ctx->idx_ctr) (void)hipFree(ctx->idx_ctr);
+    if (ctx->fuse_rec) (void)hipFree(ctx->fuse_rec);
     if (ctx->sticky) (void)hipFree(ctx->sticky);
     if (ctx->st_img) (void)hipFree(ctx->st_img);
     if (ctx->st_pack) (void)hipFree(ctx->st_pack);
@@ -388,7 +392,21 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
         span_end(ctx);
         return DBDE_HIP_OK;
     }
-    if (!self_index) {
+    // Few large frames (one 4096x3072 frame per call: 384 chunks): the decode workgroups build the index among
+    // themselves (decode_kernel<IMG, kIdxFused>) -- no index kernel, no launch boundary.  Taken when the launch fits the
+    // device's workgroup slots (four per CU); correctness does not depend on that, only the latency does.
+    const bool fused = !self_index && n_chunks64 <= 4ull * (uint64_t)ctx->n_cu && !(ctx->exp_flags & 8u);
+    if (fused) {
+        const size_t had = ctx->fuse_rec_n;
+        int rc = grow(ctx, ctx->fuse_rec, ctx->fuse_rec_n, (size_t)n_chunks64, sizeof(unsigned long long), true);
+        if (rc) return rc;
+        if (ctx->fuse_rec_n != had || ctx->fuse_epoch == 0xFFFFFFFFu) {   // a fresh block (or the epoch wrapping): epoch 0 everywhere
+            HIP_TRY(ctx, hipMemsetAsync(ctx->fuse_rec, 0, ctx->fuse_rec_n * sizeof(unsigned long long), ctx->stream));
+            ctx->fuse_epoch = 0;
+        }
+        ctx->fuse_epoch++;
+    }
+    if (!self_index && !fused) {
         int rc = grow(ctx, ctx->chunk_off, ctx->chunk_off_n, (size_t)n_chunks64 + (size_t)n_frames, sizeof(uint32_t));
         if (rc) return rc;
         rc = grow(ctx, ctx->frame_ok, ctx->frame_ok_n, (size_t)n_frames, sizeof(uint32_t));
@@ -447,9 +465,12 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.chunks_per_frame = dcpf;
     p.n_chunks = (uint32_t)n_chunks64;
     p.magic_W = div_magic_of((uint32_t)W);
+    p.fuse_rec = ctx->fuse_rec;
+    p.fuse_epoch = ctx->fuse_epoch;
+    p.fuse_flags = (ctx->exp_flags & 16u) ? 1u : 0u;
     p.geom = dg;
     span_begin(ctx, 2);
-    HIP_TRY(ctx, launch_decode(p, img_mode, self_index, ctx->stream));
+    HIP_TRY(ctx, launch_decode(p, img_mode, self_index ? 1 : (fused ? 2 : 0), ctx->stream));
     span_end(ctx);
     return DBDE_HIP_OK;
 }

@@ -107,6 +107,9 @@ struct DecParams {
     uint32_t w, h, T;
     uint32_t chunks_per_frame, n_chunks;
     uint32_t magic_W;               // div_magic_of(W): byte offset in a chunk's range -> (image row, column), staged copy-out
+    unsigned long long *fuse_rec;   // index_mode 2: [n_chunks] records {epoch 32 | depth > 8 seen 1 | payload words 31}
+    uint32_t fuse_epoch;            // ... of THIS launch (never 0; records of other launches do not match)
+    uint32_t fuse_flags;            // bit 0 (tests): odd chunks publish nothing -- the waiting waves' fallback does the work
     DecGeom geom;
 };
 
@@ -140,8 +143,10 @@ hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_ou
 int encode_blocks_per_cu();
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
-// self_index: no index kernel ran; every workgroup validates the frame and finds its offset itself (few frames)
-hipError_t launch_decode(const DecParams &p, int img_mode, bool self_index, hipStream_t s);
+// index_mode: 0 = chunk_off / frame_ok come from launch_decode_index; 1 = no index kernel, every workgroup reads the
+// frame's whole depth array (few small frames); 2 = no index kernel either, the workgroups exchange their chunks' depth
+// sums through p.fuse_rec (few LARGE frames: launches that fit the device's workgroup slots)
+hipError_t launch_decode(const DecParams &p, int img_mode, int index_mode, hipStream_t s);
 // Frames of at most 64 tiles: one tile per lane, 64 / T frames per wave, validation and offsets by a segmented wave scan
 // (no index kernel, no workspace).
 hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t s);

@@ -1502,8 +1502,20 @@ constexpr int kImgDirect = 0, kImgLinear = 1, kImgTiles = 2;
 // index kernel and its launch boundary: EVERY workgroup reads the frame's whole depth array (T bytes, from L2
 // after the first touch), which gives it the reference's validation verdict (dbde_util.cpp:295-303) and the word
 // offset of its own chunk.  T bytes per workgroup only pays while frames * chunks * T stays small (dbde_capi.cpp).
-template <int IMG, bool SELF_INDEX>
+// FUSED (kIdxFused): launches of few LARGE frames (one 4096x3072 frame per call: 384 chunks; the whole-array read of
+// SELF_INDEX took 38 us there, index kernel + boundary + decode 12.4 us).  The launch's workgroups build the index
+// among themselves: each sums ITS chunk's depth bytes (it needs them anyway) and publishes the sum as an 8-byte record
+// tagged with the launch's epoch (relaxed agent-scope store to uncached memory; records of older launches carry older
+// epochs, so nothing is cleared between launches); wave 0 then reads the records of the frame's chunks -- its prefix,
+// the frame's word count for the n64 check (dbde_util.cpp:302-303) and the depth <= 8 verdict are sums over them.
+// Co-residency is the normal case (the host takes this form only for launches that fit the device's workgroup slots)
+// but nothing depends on it: a record that has not appeared after 30 us is computed by the waiting wave itself from
+// the stream (the chunk's 512 depth bytes) -- every spin ends, whatever the dispatch order.
+constexpr int kIdxTable = 0, kIdxSelf = 1, kIdxFused = 2;
+
+template <int IMG, int INDEX>
 __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
+    constexpr bool SELF_INDEX = INDEX == kIdxSelf;
     typedef DecLds G;
     __shared__ __attribute__((aligned(16))) uint64_t s_in[G::kSlots * 2];
     __shared__ uint32_t s_wave_tot[G::kWaves];
@@ -1600,6 +1612,107 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         if (!okf) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
         w_begin = before;
         w_end = before + mine;
+    } else if (INDEX == kIdxFused) {
+        const uint32_t T = p.T, cpf = p.chunks_per_frame;
+        const uint64_t need = 32ull + 2ull * T;
+        const bool in_range = in_extent(foff, need, p.stream_bytes);
+        uint32_t field = 0;
+        uint64_t index = 0, elapsed = 0;
+        const bool record = cf == 0u && tid == 0 && p.results;
+        if (record && in_extent(foff, 20, p.stream_bytes)) {
+            field = load_u32_bytes(fb);
+            index = load_u64_bytes(fb + 4);
+            elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
+        }
+        FrameResultDev *res = reinterpret_cast<FrameResultDev *>(p.results) + f;
+        if (!in_range) {   // every workgroup of the frame sees this by itself: nobody publishes, nobody waits
+            if (record) { res->u64s = 0xFFFFFFFFu; res->pad_ = 0; res->index = index; res->elapsed_ns = elapsed; res->consumed = 20ull; }
+            return;
+        }
+        // 1. this chunk's depth sum and "a depth above 8" verdict
+        const uint8_t *darr = fb + 24;
+        const uint32_t te = t_begin + 2u * (uint32_t)tid;
+        uint32_t dsum = 0, dbad = 0;
+        if (2u * (uint32_t)tid < n_tiles) { const uint32_t d = darr[te]; dsum += d; dbad |= d > 8u ? 1u : 0u; }
+        if (2u * (uint32_t)tid + 1u < n_tiles) { const uint32_t d = darr[te + 1u]; dsum += d; dbad |= d > 8u ? 1u : 0u; }
+        dsum = wave_sum(dsum);
+        const bool wbad = __any((int)dbad);
+        if (lane == 0) { s_idx[wave][0] = dsum; s_idx[wave][1] = wbad ? 1u : 0u; }
+        __syncthreads();
+        unsigned long long *rec = p.fuse_rec + (size_t)f * cpf;
+        const unsigned long long tag = (unsigned long long)p.fuse_epoch << 32;
+        if (tid == 0 && !((p.fuse_flags & 1u) && (cf & 1u))) {   // (fuse_flags bit 0, tests: odd chunks keep silent, as if not running)
+            uint32_t mine = 0, mbad = 0;
+#pragma unroll
+            for (int k = 0; k < G::kWaves; k++) { mine += s_idx[k][0]; mbad |= s_idx[k][1]; }
+            __hip_atomic_store(&rec[cf], tag | ((unsigned long long)mbad << 31) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // 2. wave 0: the records of the frame's chunks
+        if (wave == 0) {
+            const uint64_t t_start = wall_clock64();
+            uint32_t before = 0, total = 0, flag = 0;
+            for (uint32_t base = 0; base < cpf; base += 64u) {
+                const uint32_t k = base + (uint32_t)lane;
+                unsigned long long w = 0;
+                bool got = k >= cpf;
+                for (;;) {
+                    if (!got) { w = __hip_atomic_load(&rec[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = (w >> 32) == (tag >> 32); }
+                    if (__all((int)got)) break;
+                    if (wall_clock64() - t_start > 3000ull) {   // 30 us: whoever has not published may not be running yet
+                        uint64_t miss = __ballot((int)!got);
+                        while (miss) {                           // its chunk's depth bytes, eight per lane, summed here
+                            const uint32_t kk = (uint32_t)__builtin_ctzll(miss);
+                            miss &= miss - 1ull;
+                            const uint32_t c_lo = dec_chunk_begin(p.geom, base + kk), c_hi = dec_chunk_begin(p.geom, base + kk + 1u);
+                            uint32_t sm = 0, bd = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; j += 4u) {
+                                const uint32_t q = c_lo + (uint32_t)lane * 8u + j;
+                                if (q < c_hi) {
+                                    uint32_t x;
+                                    __builtin_memcpy(&x, darr + q, 4);
+                                    const uint32_t keep = c_hi - q;
+                                    if (keep < 4u) x &= 0xFFFFFFFFu >> (8u * (4u - keep));
+                                    bd |= depth_bytes_bad(x, 1u);
+                                    sm += __builtin_amdgcn_sad_u8(x, 0u, 0u);
+                                }
+                            }
+                            sm = wave_sum(sm);
+                            const bool anyb = __any((int)(bd != 0u));
+                            if ((uint32_t)lane == kk) { w = tag | ((unsigned long long)(anyb ? 1u : 0u) << 31) | sm; got = true; }
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t v = k < cpf ? (uint32_t)w & 0x7FFFFFFFu : 0u;
+                total += v;
+                before += k < cf ? v : 0u;
+                flag |= k < cpf ? (uint32_t)(w >> 31) & 1u : 0u;
+            }
+            before = wave_sum(before); total = wave_sum(total);
+            const bool anyflag = __any((int)flag);
+            if (lane == 0) { s_idx[0][2] = before; s_idx[0][3] = total; s_idx[1][2] = anyflag ? 1u : 0u; }
+        }
+        __syncthreads();
+        const uint32_t before = s_idx[0][2], total = s_idx[0][3], flag = s_idx[1][2];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < G::kWaves; k++) mine += s_idx[k][0];
+        const int32_t nb = (int32_t)load_u32_bytes(fb + 20);
+        const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
+        const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
+        const bool okf = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && !flag &&
+                         in_extent(foff, need + 8ull * total, p.stream_bytes);
+        if (record) {
+            res->u64s = (field == 2u && okf) ? 2u : 0xFFFFFFFFu;   // dbde_util.cpp:335,342
+            res->pad_ = 0; res->index = index; res->elapsed_ns = elapsed;
+            res->consumed = okf ? need + 8ull * total : 20ull;
+        }
+        if (!okf) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
+        w_begin = before;
+        w_end = before + mine;
+        __syncthreads();   // s_idx and s_wave_tot are about to be reused
     } else {
         // everything the address arithmetic needs, requested together
         const uint32_t ok = p.frame_ok[f];
@@ -1998,15 +2111,20 @@ hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t launch_decode(const DecParams &p, int img_mode, bool self_index, hipStream_t s) {
+template <int IMG>
+static void launch_decode_img(const DecParams &p, int index_mode, dim3 grid, dim3 block, hipStream_t s) {
+    switch (index_mode) {
+        case kIdxTable: hipLaunchKernelGGL((decode_kernel<IMG, kIdxTable>), grid, block, 0, s, p); break;
+        case kIdxSelf: hipLaunchKernelGGL((decode_kernel<IMG, kIdxSelf>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((decode_kernel<IMG, kIdxFused>), grid, block, 0, s, p); break;
+    }
+}
+hipError_t launch_decode(const DecParams &p, int img_mode, int index_mode, hipStream_t s) {
     dim3 grid(p.n_chunks), block(kChunkTiles / 2);
-    switch (img_mode * 2 + (self_index ? 1 : 0)) {
-        case kImgDirect * 2 + 0: hipLaunchKernelGGL((decode_kernel<kImgDirect, false>), grid, block, 0, s, p); break;
-        case kImgDirect * 2 + 1: hipLaunchKernelGGL((decode_kernel<kImgDirect, true>), grid, block, 0, s, p); break;
-        case kImgLinear * 2 + 0: hipLaunchKernelGGL((decode_kernel<kImgLinear, false>), grid, block, 0, s, p); break;
-        case kImgLinear * 2 + 1: hipLaunchKernelGGL((decode_kernel<kImgLinear, true>), grid, block, 0, s, p); break;
-        case kImgTiles * 2 + 0: hipLaunchKernelGGL((decode_kernel<kImgTiles, false>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((decode_kernel<kImgTiles, true>), grid, block, 0, s, p); break;
+    switch (img_mode) {
+        case kImgDirect: launch_decode_img<kImgDirect>(p, index_mode, grid, block, s); break;
+        case kImgLinear: launch_decode_img<kImgLinear>(p, index_mode, grid, block, s); break;
+        default: launch_decode_img<kImgTiles>(p, index_mode, grid, block, s); break;
     }
     return hipGetLastError();
 }

@@ -73,9 +73,13 @@ int main(int argc, char **argv) {
     CK(hipMemsetAsync(diff, 0, 8, s));
     CK(hipMemsetAsync(out, 0xEE, px * B, s));
     if (dbde_hip_synth_frames(c, mode, 0xDBDE2016ull, 0, B, W, H, img)) { fprintf(stderr, "synth: %s\n", dbde_hip_last_error(c)); return 1; }
+    const char *only = getenv("ABBENCH_ONLY");   // "enc" / "dec": the timed loop runs one direction only (the other ran in the warm-up)
+    bool timed = false;
     auto step = [&]() -> int {
-        if (dbde_hip_encode_frames(c, img, W, H, B, 0, nullptr, nullptr, buf + 32, cap, slot, offs, sizes)) return 1;
-        if (dbde_hip_decode_frames(c, buf + 32, cap, offs, W, H, B, out, nullptr)) return 1;
+        if (!(timed && only && !strcmp(only, "dec")))
+            if (dbde_hip_encode_frames(c, img, W, H, B, 0, nullptr, nullptr, buf + 32, cap, slot, offs, sizes)) return 1;
+        if (!(timed && only && !strcmp(only, "enc")))
+            if (dbde_hip_decode_frames(c, buf + 32, cap, offs, W, H, B, out, nullptr)) return 1;
         return 0;
     };
     for (int i = 0; i < 2; i++) if (step()) { fprintf(stderr, "step: %s\n", dbde_hip_last_error(c)); return 1; }
@@ -98,6 +102,7 @@ int main(int argc, char **argv) {
         uint64_t junk[16];
         if (dr) dr(c, junk);
     }
+    timed = true;
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < steps; i++) if (step()) return 1;
     if (dbde_hip_sync(c)) { fprintf(stderr, "sync: %s\n", dbde_hip_last_error(c)); return 1; }

@@ -316,6 +316,13 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.grid_blocks = ctx->enc_grid;
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
 
+    if (g.T <= 64u && slot_stride != 0) {   // tiny frames in slots: several frames per wave, nothing shared (encode_tiny_kernel)
+        span_begin(ctx, 0);
+        HIP_TRY(ctx, launch_encode_tiny(p, (uint32_t)n_frames, ctx->stream));
+        span_end(ctx);
+        return DBDE_HIP_OK;
+    }
+
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
     {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
         const size_t had = ctx->lb_bytes;

@@ -141,6 +141,8 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
 // self-cleaning workspace (records and counters are zero on entry and on exit).
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
+// Frames of at most 64 tiles, one slot per frame: one tile per lane, 64 / T frames per wave, no workspace.
+hipError_t launch_encode_tiny(const EncParams &p, uint32_t n_frames, hipStream_t s);
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // img_mode: 0 direct (cache-line friendly geometry), 1 staged linear ranges (W % 8 == 0), 2 tile by tile (any)
 // index_mode: 0 = chunk_off / frame_ok come from launch_decode_index; 1 = no index kernel, every workgroup reads the

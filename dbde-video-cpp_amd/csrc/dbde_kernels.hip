@@ -861,11 +861,25 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         cur = nxt;
         nxt = chunk_ref(p, lb_ok ? next_id : 0xFFFFFFFFu, tid);
     };
+#ifdef DBDE_DIAG
+    uint32_t dg_pair = 0;
+    uint64_t dg_tp = __builtin_amdgcn_s_memtime(), dg_early = 0, dg_late = 0;
+#endif
     do {
         step(0u, r0a, r0b, r1a, r1b);
         step(1u, r1a, r1b, r0a, r0b);
+#ifdef DBDE_DIAG
+        {   // how long a pair of steps takes early in the launch (pairs 2..9) and later (pairs 34..41)
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            if (dg_pair >= 2u && dg_pair < 10u) dg_early += t - dg_tp;
+            if (dg_pair >= 34u && dg_pair < 42u) dg_late += t - dg_tp;
+            dg_tp = t;
+            dg_pair++;
+        }
+#endif
     } while (cur.valid || prev.valid);
 #ifdef DBDE_DIAG
+    if (tid == 0) { atomicAdd(&p.diag[15], dg_early); atomicAdd(&p.diag[13], dg_late); }
     if (tid == 0) {
         atomicAdd(&p.diag[0], dg_wait);
         atomicAdd(&p.diag[1], dg_nwait);
@@ -874,9 +888,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         atomicAdd(&p.diag[8], 1ull);
         atomicAdd(&p.diag[9], dg_npoll);
         atomicAdd(&p.diag[10], dg_first);
-        const unsigned long long t = wall_clock64();   // ... and when they leave
-        atomicMax(&p.diag[13], ~t);
-        atomicMax(&p.diag[14], t);
+        atomicMax(&p.diag[14], wall_clock64());   // ... and when the last one leaves
     }
 #endif
 }
@@ -1015,6 +1027,62 @@ hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_ou
         case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInBytes, true>), grid, block, 0, s, p); break;
         default: hipLaunchKernelGGL((encode_small_kernel<kInBytes, false>), grid, block, 0, s, p); break;
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// ENCODE, tiny frames (T <= 64 tiles), one slot per frame: one tile per lane, several frames per wave
+// ---------------------------------------------------------------------------------------
+// The mirror of decode_tiny_kernel (the reference's randomized test packs 1024 single-tile frames,
+// dbde_util_test.cpp:66-96): a 1024-tile chunk per frame leaves the lanes empty and a record round trip per frame is all
+// the kernels above would do.  A lane owns ONE tile (clamp-to-edge load: the constant padding of dbde_util.cpp:105-135),
+// a wave 64 / T whole frames; the tile's word offset in its frame and the frame's n64 are a segmented wave scan; the
+// tile's d payload words leave the lane as they are completed (the bit funnel of dbde_bits.h).  Frames in slots depend
+// on nothing outside the frame, so there is no workspace and nothing to wait for; concatenated tiny frames keep the
+// general path.
+__global__ __launch_bounds__(256) void encode_tiny_kernel(EncParams p) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t T = p.T, fpw = 64u / T;
+    const uint32_t fl = lane / T, t = lane - fl * T;
+    const uint32_t f = (blockIdx.x * 4u + wave) * fpw + fl;
+    const bool active = fl < fpw && f < p.n_chunks;          // (n_chunks carries the frame count here)
+    uint32_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = 0;
+    if (active) load_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
+    uint32_t mn, mx;
+    tile_minmax(v, mn, mx);
+    const uint32_t d = active ? depth_of_range(mx - mn) : 0u;
+    const uint32_t incl = wave_scan_incl(d);
+    const uint32_t first = fl * T;
+    const uint32_t base = (uint32_t)__shfl((int)(incl - d), (int)(first < 64u ? first : 0u), 64);
+    const uint32_t upto = (uint32_t)__shfl((int)incl, (int)(first + T - 1u < 64u ? first + T - 1u : 63u), 64);
+    if (!active) return;
+    const uint32_t prefix = incl - d - base, total = upto - base;
+    uint8_t *fb = p.out + (uint64_t)f * p.slot_stride;
+    fb[24u + t] = (uint8_t)d;
+    fb[28u + T + t] = (uint8_t)mn;
+    uint8_t *dst = fb + 32ull + 2ull * T + 8ull * prefix;
+    const uint32_t mn4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
+    Funnel fn;
+    fn.reset();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint64_t word;
+        if (d != 0u && fn.push(pack_row(v[2 * r] - mn4, v[2 * r + 1] - mn4, d), 8u * d, word)) {
+            store_u64_any(dst, word);
+            dst += 8;
+        }
+    }
+    if (t == 0u) write_frame_fields<false>(p, f, 0u, total, 0u);   // header, the I32 fields, per-frame offset and size
+}
+
+hipError_t launch_encode_tiny(const EncParams &p, uint32_t n_frames, hipStream_t s) {
+    EncParams q = p;
+    q.n_chunks = n_frames;
+    q.chunks_per_frame = 1u;     // write_frame_fields: the one "chunk" is the frame's first and last
+    const uint32_t per_wg = 4u * (64u / p.T);
+    hipLaunchKernelGGL(encode_tiny_kernel, dim3((n_frames + per_wg - 1u) / per_wg), dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

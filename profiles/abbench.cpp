@@ -119,10 +119,11 @@ int main(int argc, char **argv) {
                     "scanner per launch: %.0f rounds, %.1f %% idle, %.1f records/round, %.0f cyc\n", tag, content,
                     d[2] / wg, d[0] / wg, 100.0 * d[0] / d[2], d[1] / wg, (double)d[9] / (d[1] ? d[1] : 1), 100.0 * d[10] / (d[1] ? d[1] : 1), d[7] / wg, 100.0 * d[7] / d[2],
                     (double)d[3] / steps, 100.0 * d[4] / (d[3] ? d[3] : 1), (double)d[6] / (d[3] ? d[3] : 1), (double)d[5] / steps);
-            if (d[11] && steps == 1) {   // one timed launch: when its workgroups started and left (10 ns wall clock)
+            if (d[11] && steps == 1) {   // one timed launch: when its workgroups started and the last one left (10 ns wall clock)
                 const double t0 = (double)(~d[11]);
-                fprintf(stderr, "diag[%s]: workgroups start within %.1f us; first leaves at %.1f us, last at %.1f us after the first start\n", tag,
-                        ((double)d[12] - t0) / 100.0, ((double)(~d[13]) - t0) / 100.0, ((double)d[14] - t0) / 100.0);
+                fprintf(stderr, "diag[%s]: workgroups start within %.1f us, the last leaves %.1f us after the first start; a pair of steps takes "
+                        "%.0f cyc early in the launch (pairs 2-9), %.0f cyc later (pairs 34-41)\n", tag,
+                        ((double)d[12] - t0) / 100.0, ((double)d[14] - t0) / 100.0, d[15] / wg / 8.0, d[13] / wg / 8.0);
             }
         }
     }

@@ -703,3 +703,26 @@ def test_seeded_fuzz_against_oracle(codec, oracle):
         back2, _ = codec.decode_frames(sbuf, mis2, slen, offs2, W, H, n)
         codec.sync()
         assert torch.equal(back, imgs) and torch.equal(back2, imgs), (case, W, H, n, slot, mis, mis2)
+
+
+@pytest.mark.parametrize("W,H,n", [(8, 8, 1000), (64, 64, 300), (10, 10, 77), (33, 31, 50), (24, 16, 5), (1, 1, 9), (512, 8, 40),
+                                   (7, 300, 33), (61, 59, 129)])
+@pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
+def test_tiny_frames_many_per_wave(codec, oracle, W, H, n, mode):
+    """Frames of at most 64 tiles (the reference's randomized test is 1024 single-tile frames, dbde_util_test.cpp:66-96):
+    one tile per lane, several frames per wave in both directions (encode_tiny_kernel for slots, decode_tiny_kernel);
+    every frame byte for byte against the oracle, both layouts, partial tiles, a frame count that leaves lanes idle."""
+    import torch
+    imgs = codec.synth_frames(mode, SEED, 50, n, W, H)
+    imgs_h = imgs.cpu().numpy()
+    slot_bytes = ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
+    for slot in (slot_bytes, 0):
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=50, slot_stride=slot)
+        for f in range(n):
+            assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
+        total = int((offs[-1] + sizes[-1]).item())
+        canvas = torch.full_like(imgs, 0xEE)
+        back, res = codec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
+        codec.sync()
+        assert torch.equal(back, imgs), (W, H, mode, slot)
+        assert codec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]

@@ -102,6 +102,26 @@ def progress(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Libraries below us write banners to file descriptor 1 (RCCL prints its version block there when a communicator is
+    created).  The contract is ONE JSON line on stdout: everything else written to fd 1 goes to stderr from here on, and
+    emit() writes the line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def cpu_baseline(make_frames, W, H, budget_s=8.0):
     """Reference (oracle/_ref, kind 'reference') or oracle port on ALL the host cores this job may use: every
     thread round-trips its own frame until the budget has passed (the reference's own timing loop brackets
@@ -418,13 +438,13 @@ def dry_run(args, world, rank, dist):
         stream, sizes = dd.gather_stream(seg, seg.numel(), dst=0)
         gathered = sum(sizes)
     if rank == 0:
-        print(json.dumps({"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "value": 0.0,
+        emit({"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "value": 0.0,
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u8",
                           "data": "none (dry run: launch contract only, no GPU work, not a measurement)",
                           "dry_run": True, "frames_of_rank0": [lo, hi], "gathered_bytes": gathered,
-                          "config": {"workload": "dry run"}}), flush=True)
+                          "config": {"workload": "dry run"}})
 
 
 def main():
@@ -455,6 +475,7 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
+    quiet_stdout()
     import torch
     dist = None
     # rehearsal on a one-GPU box: DBDE_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo (exercises the
@@ -592,7 +613,7 @@ def main():
             def give_up():
                 if rank == 0:
                     line["gather"] = {"error": "the exchange leg did not finish within 300 s (a collective was never answered)"}
-                    print(json.dumps(line), flush=True)
+                    emit(line)
 
             with Watchdog(300.0, give_up):
                 for mode in ([gather_mode, "nccl"] if gather_mode == "native" else [gather_mode]):
@@ -620,7 +641,7 @@ def main():
             progress("cpu baseline")
             mk = lambda content, n: b.codec.synth_frames(content, SEED, 0, n, 4096, 3072).cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(mk, 4096, 3072)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         if gather_failed:    # the communicator may be unusable: leave without the farewell collective
             sys.stdout.flush()

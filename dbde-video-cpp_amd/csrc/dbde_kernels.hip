@@ -688,8 +688,10 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     // before the last on a 1-4 ms launch).  The last kTailRounds rounds of chunk ids -- everything from s_static on, the
     // same boundary for every workgroup -- are therefore drawn as tickets (ctrl[0]) even in static mode: ids stay dense, a
     // ticket belongs to a running workgroup, and a fast workgroup simply draws more of them.
+    // (A workgroup's first two chunks, rank and rank + G, are always static: the boundary lies at 2 G or above.)
     constexpr uint32_t kTailRounds = 3;
-    const uint32_t s_static = p.n_chunks > (kTailRounds + 1u) * G ? (p.n_chunks / G - kTailRounds) * G : 0xFFFFFFFFu;
+    const uint32_t full_rounds = p.n_chunks / G;
+    const uint32_t s_static = full_rounds >= kTailRounds + 2u ? (full_rounds - kTailRounds) * G : 0xFFFFFFFFu;
     ChunkRef nxt = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[0]), tid);
     ChunkRef prev = chunk_ref(p, 0xFFFFFFFFu, tid);
     uint64_t *pay = sh.pay[wave];

@@ -3,7 +3,7 @@
 and spot-checked against the oracle's bytes.  Looks for rare, timing-dependent corruption in the
 persistent encoder (hand-placed waits, cross-workgroup hand-off), which short parity tests could miss.
 
-    python tests/soak.py [--rounds 40] [--seed 1]   (test infrastructure: the oracle is its checker; log: profiles/soak_r02.log)
+    python tests/soak.py [--rounds 40] [--seed 1]   (test infrastructure: the oracle is its checker; logs: profiles/soak_r0N.log)
 """
 import argparse
 import os
@@ -25,13 +25,17 @@ ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 codec, ora = dv.Codec(0), Oracle()
-shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080), (1001, 999), (1366, 768), (641, 481), (1928, 1080)]
+# (the last six: tiny-frame kernels, T <= 64; with n in {1, 3} the large shapes take the fused index + decode launch)
+shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080), (1001, 999), (1366, 768), (641, 481), (1928, 1080),
+          (1921, 1081), (1001, 999), (64, 64), (8, 8), (61, 59), (33, 31), (512, 8), (24, 16)]
 t0 = time.time()
 frames_done = 0
 for r in range(a.rounds):
     W, H = shapes[int(rng.integers(0, len(shapes)))]
     per = W * H
     n = int(rng.choice([1, 3, 17, 64, 200, 512, 1024]))
+    if per <= 64 * 64:
+        n = int(rng.choice([1, 7, 1000, 30000, 200000]))     # tiny frames: many per wave
     n = max(1, min(n, int(9e9 // per)))
     content = str(rng.choice(["noise8", "mixed", "smooth", "flat"]))
     concat = bool(rng.integers(0, 2)) and n * 8 * dv.tiles(W, H) < 2**32

@@ -726,3 +726,24 @@ def test_tiny_frames_many_per_wave(codec, oracle, W, H, n, mode):
         codec.sync()
         assert torch.equal(back, imgs), (W, H, mode, slot)
         assert codec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
+
+
+@pytest.mark.parametrize("W,H,n,mode,concat", [(1921, 1081, 64, "noise8", True), (2048, 1024, 70, "mixed", False),
+                                               (2048, 1024, 48, "mixed", True), (2048, 1024, 80, "smooth", False),
+                                               (2048, 1024, 97, "mixed", True)])
+def test_persistent_encoder_chunk_counts_around_the_ticket_boundary(codec, oracle, W, H, n, mode, concat):
+    """The persistent encoder hands out the ids of the last three rounds as tickets even in static mode; the first two
+    chunks of a workgroup (rank, rank + G) are always static.  Launches of 3 G ... 6 G chunks sit on every side of that
+    boundary (a soak run found 4 G <= chunks < 5 G handing the ids G ... 2 G out twice: look-back time-out)."""
+    import torch
+    imgs = codec.synth_frames(mode, SEED, 7, n, W, H)
+    slot = 0 if concat else ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
+    for rep in range(2):
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=7, slot_stride=slot)
+    imgs_h = imgs.cpu().numpy()
+    for f in (0, 1, n // 2, n - 2, n - 1):
+        assert frames[f].tobytes() == oracle.pack_frame(7 + f, imgs_h[f], W, H).tobytes(), f
+    cap = (n - 1) * slot + codec.L.dbde_hip_max_frame_bytes(W, H) if slot else int((offs[-1] + sizes[-1]).item())
+    back, res = codec.decode_frames(buf, lead, cap, offs, W, H, n)
+    codec.sync()
+    assert torch.equal(back, imgs)

@@ -35,7 +35,11 @@ def test_committed_bench_lines_follow_the_contract():
     if r["traffic"] is not None:
         assert 0.98 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05 and r["traffic_source"]
     # the path that really bit-packs and the other single-GPU configs are in the same line
-    assert d["contents"]["mixed"]["identical"] and set(d["configs"]) == {"3", "4"}
+    assert d["contents"]["mixed"]["identical"] and {"3", "4"} <= set(d["configs"])
+    # every timed configuration that has a reference-made fixture was also checked against it (not identity alone)
+    assert d["contents"]["mixed"]["packed_sha_ok"] is True
+    assert all(d["configs"][k]["packed_sha_ok"] is True for k in ("3", "4"))
+    assert d["cpu_baseline"]["mixed"]["value"] > 0 and d["cpu_baseline"]["mixed"]["mismatched_pixels"] == 0
     for k in CPU:
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["mismatched_pixels"] == 0

@@ -616,6 +616,55 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
     if ((uint64_t)n_frames * cpf >= (1ull << 31) || (uint64_t)g.T * 16ull >= (1ull << 32))
         return fail(ctx, DBDE_HIP_ERR_ARG, "encode16: launch too large");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // Large launches of 16-byte aligned rows go through the 8-bit path's persistent encoder (encode_kernel<.., PIX = 2>:
+    // central scanner, register prefetch, wave-private payload images, one barrier per 512-tile chunk).  Its prefixes
+    // are 32-bit word counts (30 bits inside a frame); everything else -- odd widths, launches the device is not
+    // filled by, batches past those limits -- stays with enc16_kernel below.
+    {
+        const uint32_t cpf2 = (g.T + kEncChunkTiles / 2u - 1u) / (kEncChunkTiles / 2u);
+        const uint64_t n_chunks64 = (uint64_t)n_frames * cpf2;
+        const bool fits = 16ull * g.T < (1ull << 30) && (slot_stride != 0 || (uint64_t)n_frames * 16ull * g.T < (1ull << 32));
+        if (W % 8 == 0 && (reinterpret_cast<uintptr_t>(d_images) & 15u) == 0 && fits && n_chunks64 >= ctx->enc_grid &&
+            n_chunks64 < (1ull << 31) && !(ctx->exp_flags & 32u)) {
+            EncParams q;
+            q.images = reinterpret_cast<const uint8_t *>(d_images);
+            q.out = d_out;
+            q.frame_offsets = d_frame_offsets;
+            q.frame_bytes = d_frame_bytes;
+            q.indices = nullptr;
+            q.elapsed_ns = nullptr;
+            q.first_index = first_index;
+            q.sticky = ctx->sticky;
+            q.slot_stride = slot_stride;
+            q.frame_pixels = 2ull * g.pixels;   // bytes
+            q.W = W; q.H = H; q.w = g.w; q.h = g.h; q.T = g.T;
+            q.chunks_per_frame = cpf2;
+            q.lanes_per_row = 0;
+            q.magic_w = div_magic_of(g.w);
+            q.magic_cpf = div_magic_of(cpf2);
+            q.magic_lpr = div_magic_of(0);
+            q.last_frame = (uint32_t)n_frames - 1u;
+            q.n_chunks = (uint32_t)n_chunks64;
+            q.flags = ctx->exp_flags;
+            q.grid_blocks = ctx->enc_grid;
+            q.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
+            const size_t lb_need = (16 + 8 * (size_t)q.n_chunks + 15) & ~(size_t)15;
+            const size_t had = ctx->lb_bytes;
+            int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);
+            if (rc) return rc;
+            if (ctx->lb_bytes != had) ctx->lb_clean = false;
+            const bool aligned_out = (reinterpret_cast<uintptr_t>(d_out) & 7u) == 0 && g.T % 8 == 0 && slot_stride % 8 == 0;
+            span_begin(ctx, 0);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
+            ctx->lb_clean = false;
+            q.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
+            q.state = reinterpret_cast<unsigned long long *>(ctx->lb + 16);
+            HIP_TRY(ctx, launch_encode16_fast(q, aligned_out, ctx->stream));
+            span_end(ctx);
+            return DBDE_HIP_OK;
+        }
+    }
     // workspace, zeroed before the launch: [ticket 16 B][state 8 n cpf][gsum 8 n gpf][fsize 8 n][fgsum 8 ceil(n / 64)]
     const size_t n = (size_t)n_frames, gpf = (cpf + 63) / 64;
     const size_t need = 16 + 8 * (n * cpf + n * gpf + n + (n + 63) / 64);

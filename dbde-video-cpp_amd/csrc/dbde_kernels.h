@@ -79,7 +79,7 @@ struct EncParams {
     uint32_t *ctrl;                // [1] scanner claim, [2] arrivals + tickets, [3] claim mode; zeroed before the launch
     uint32_t *sticky;              // context-wide failure word, OR-ed on look-back time-out
     uint64_t slot_stride;          // 0 = frames concatenated
-    uint64_t frame_pixels;         // W*H
+    uint64_t frame_pixels;         // W*H: BYTES of one frame's image (2 W H for launch_encode16_fast)
     int W, H;
     uint32_t w, h, T;              // tiles across, down, total
     uint32_t chunks_per_frame, n_chunks;
@@ -137,6 +137,8 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 };
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
+// DBDE16 (U16 pixels, W % 8 == 0, 16-byte aligned base) through the persistent encoder: 512 tiles per chunk, frame_pixels in bytes
+hipError_t launch_encode16_fast(const EncParams &p, bool aligned_out, hipStream_t s);
 // Launches with at most as many chunks as the device holds workgroups: one workgroup per chunk, no scanner,
 // self-cleaning workspace (records and counters are zero on entry and on exit).
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);

@@ -199,10 +199,11 @@ __device__ __forceinline__ void load_tile_generic(const uint8_t *img, int W, int
 //   AGG : [63:62] = 1, [31:0] payload words of the chunk
 //   INC : [63:62] = 2, [61:32] payload words of the frame up to and including the chunk,
 //                      [31:0]  payload words of the launch up to and including it (mod 2^32)
-template <bool ALIGNED_OUT>
+// PIX = bytes per pixel: 1 = DBDE, 2 = DBDE16 (U16 minima: nm = 2T, 32 + 3T bytes in front of the payload).
+template <bool ALIGNED_OUT, int PIX = 1>
 __device__ __forceinline__ void write_frame_fields(const EncParams &p, uint32_t f, uint32_t cf, uint32_t inf_incl,
                                                      uint32_t frame_start_glob) {
-    const uint64_t meta = 32ull + 2ull * p.T;
+    const uint64_t meta = 32ull + (uint64_t)(1 + PIX) * p.T;
     const uint64_t frame_base = p.slot_stride ? (uint64_t)f * p.slot_stride
                                               : (uint64_t)f * meta + 8ull * (uint64_t)frame_start_glob;
     uint8_t *fb = p.out + frame_base;
@@ -216,19 +217,19 @@ __device__ __forceinline__ void write_frame_fields(const EncParams &p, uint32_t 
             h[1] = (uint32_t)index; h[2] = (uint32_t)(index >> 32);
             h[3] = (uint32_t)elbits; h[4] = (uint32_t)(elbits >> 32);
             h[5] = p.T;
-            *reinterpret_cast<uint32_t *>(fb + 24 + p.T) = p.T;
+            *reinterpret_cast<uint32_t *>(fb + 24 + p.T) = (uint32_t)PIX * p.T;
         } else {
             store_u32_bytes(fb, 2u);
             store_u32_bytes(fb + 4, (uint32_t)index); store_u32_bytes(fb + 8, (uint32_t)(index >> 32));
             store_u32_bytes(fb + 12, (uint32_t)elbits); store_u32_bytes(fb + 16, (uint32_t)(elbits >> 32));
             store_u32_bytes(fb + 20, p.T);
-            store_u32_bytes(fb + 24 + p.T, p.T);
+            store_u32_bytes(fb + 24 + p.T, (uint32_t)PIX * p.T);
         }
         if (p.frame_offsets) p.frame_offsets[f] = frame_base;
     }
     if (cf == p.chunks_per_frame - 1u) {   // I32 n64 (dbde_util.cpp:144-146,179)
-        if (ALIGNED_OUT) *reinterpret_cast<uint32_t *>(fb + 28 + 2ull * p.T) = inf_incl;
-        else store_u32_bytes(fb + 28 + 2ull * p.T, inf_incl);
+        if (ALIGNED_OUT) *reinterpret_cast<uint32_t *>(fb + meta - 4ull) = inf_incl;
+        else store_u32_bytes(fb + meta - 4ull, inf_incl);
         if (p.frame_bytes) p.frame_bytes[f] = meta + 8ull * inf_incl;
     }
 }
@@ -384,6 +385,7 @@ struct ChunkRef {
     bool valid, hasA, hasB;
 };
 
+template <int PIX = 1>
 __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, int tidw) {
     ChunkRef k;
     k.c = c;
@@ -391,7 +393,11 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
     uint32_t cf = 0;
     k.f = k.valid ? div_magic(c, p.chunks_per_frame, p.magic_cpf, cf) : 0u;
     k.cf = k.valid ? cf : 0u;
-    if (p.lanes_per_row == 0u) {            // plain: 1024 consecutive tiles
+    if (PIX == 2) {                         // DBDE16: ONE tile per lane (a tile row is 16 bytes), 512 consecutive tiles
+        k.t0 = k.cf * (kEncChunkTiles / 2u) + (uint32_t)tidw;
+        k.hasA = k.hasB = k.valid && k.t0 < p.T;
+        k.ty = div_magic(k.t0, p.w, p.magic_w, k.tx);
+    } else if (p.lanes_per_row == 0u) {     // plain: 1024 consecutive tiles
         k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
         k.hasA = k.valid && k.t0 < p.T;
         k.hasB = k.valid && k.t0 + 1u < p.T;
@@ -420,9 +426,12 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
 // stay in flight.
 constexpr int kInFast = 0, kInRaw = 1, kInBytes = 2;
 
-template <int IN_MODE, bool ZERO = true>
+// PIX == 2 (DBDE16, kInFast only): the lane's 16 bytes of a row are ONE tile's eight U16 pixels -- va holds the
+// left half (pixels 0..3) of each row, vb the right half; frame_pixels counts bytes there.
+template <int IN_MODE, bool ZERO = true, int PIX = 1>
 __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                            uint32_t (&vb)[16]) {
+    static_assert(PIX == 1 || IN_MODE == kInFast, "DBDE16 has the aligned input path only");
     if (ZERO) {   // (callers that never read registers of tile-less lanes skip this)
 #pragma unroll
         for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
@@ -433,7 +442,7 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
         // at the result.  With a conditional issue the compiler cannot know how many loads are in
         // flight and makes the statistics of the CURRENT chunk wait for these as well.
         const uint32_t ty = k.hasA ? k.ty : 0u, tx = k.hasA ? k.tx : 0u;
-        const uint32_t x0 = 8u * tx;
+        const uint32_t x0 = (PIX == 2 ? 16u : 8u) * tx;   // byte column
         // kInRaw: the 16 bytes of a row's last lane run into the next image row -- harmless, those bytes are replaced by
         // the constant padding (load_fixup_generic) -- except in the last image row of the batch, where they would pass
         // the end of the caller's buffer: there, and only there, the fetch is moved left to END at the row's last pixel
@@ -443,7 +452,7 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
             int yy = 8 * (int)ty + r;
             yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
             const uint32_t xr = at_end && yy == p.H - 1 ? (uint32_t)p.W - 16u : x0;
-            const uint8_t *src = img + (size_t)yy * (size_t)p.W + xr;
+            const uint8_t *src = img + (size_t)yy * (size_t)(PIX * p.W) + xr;
             u32x4_t q;
             if (IN_MODE == kInFast) {
                 q = DBDE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(src))
@@ -559,23 +568,84 @@ __device__ __forceinline__ void pack_tile_d8(const uint32_t (&v)[16], uint32_t m
         pay[swzq8(q + (uint32_t)r)] = (uint64_t)(v[2 * r] - m4) | ((uint64_t)(v[2 * r + 1] - m4) << 32);
 }
 
+// ---- DBDE16 (PIX == 2; format: oracle/dbde16_oracle.c) -- the tile of a lane is va (left halves of the rows) + vb ----
+__device__ __forceinline__ void tile_minmax16(const uint32_t (&va)[16], const uint32_t (&vb)[16], uint32_t &mn, uint32_t &mx) {
+    uint32_t lo = pk_min_u16(va[0], vb[0]), hi = pk_max_u16(va[0], vb[0]);
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        lo = pk_min_u16(pk_min_u16(lo, va[i]), vb[i]);
+        hi = pk_max_u16(pk_max_u16(hi, va[i]), vb[i]);
+    }
+    mn = (lo & 0xFFFFu) < (lo >> 16) ? (lo & 0xFFFFu) : (lo >> 16);
+    mx = (hi & 0xFFFFu) > (hi >> 16) ? (hi & 0xFFFFu) : (hi >> 16);
+}
+// Four pixels (two dwords of two U16, already minus the minimum) -> the 4*d-bit integer p0 | p1<<d | p2<<2d | p3<<3d;
+// a pair fits 32 bits (d <= 16).
+__device__ __forceinline__ uint64_t pack4x16(uint32_t a, uint32_t b, uint32_t d) {
+    const uint32_t lo = (a & 0xFFFFu) | ((a >> 16) << d);
+    const uint32_t hi = (b & 0xFFFFu) | ((b >> 16) << d);
+    return (uint64_t)lo | ((uint64_t)hi << (2u * d));
+}
+// The tile's d payload words into the wave's LDS region from word q on: the straight-line funnel of pack_tile over
+// sixteen half rows of 4*d <= 64 bits (a tile row is the 8*d-bit integer at byte r*d of the tile's payload).
+__device__ __forceinline__ void pack_tile16(const uint32_t (&va)[16], const uint32_t (&vb)[16], uint32_t mn, uint32_t d,
+                                            uint64_t *pay, uint32_t q, uint32_t trash) {
+    const uint32_t mn2 = mn * 0x00010001u;   // every 16-bit half >= mn: no borrow crosses a half
+    const uint32_t nb = 4u * d;
+    uint32_t qq = d ? q : trash;
+    uint64_t acc = 0;
+    uint32_t fill = 0;
+#pragma unroll
+    for (int h = 0; h < 16; h++) {
+        const int r = h >> 1;
+        const uint64_t bits = (h & 1) ? pack4x16(vb[2 * r] - mn2, vb[2 * r + 1] - mn2, d)
+                                      : pack4x16(va[2 * r] - mn2, va[2 * r + 1] - mn2, d);
+        const uint64_t merged = acc | (bits << fill);
+        pay[qq] = merged;
+        const uint32_t nf = fill + nb;
+        const bool emit = nf >= 64u;
+        acc = emit ? ((bits >> 1) >> (63u - fill)) : merged;
+        fill = nf & 63u;
+        qq += emit ? 1u : 0u;
+    }
+}
+
+// Depth 16 everywhere in the wave: the payload is the min-subtracted pixels, half row by half row; lanes write at a
+// 128-byte stride, so the image is swizzled exactly as for pack_tile_d8.
+__device__ __forceinline__ void pack_tile16_d16(const uint32_t (&va)[16], const uint32_t (&vb)[16], uint32_t mn, uint64_t *pay, uint32_t q) {
+    const uint32_t mn2 = mn * 0x00010001u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        pay[swzq8(q + 2u * (uint32_t)r)] = (uint64_t)(va[2 * r] - mn2) | ((uint64_t)(va[2 * r + 1] - mn2) << 32);
+        pay[swzq8(q + 2u * (uint32_t)r + 1u)] = (uint64_t)(vb[2 * r] - mn2) | ((uint64_t)(vb[2 * r + 1] - mn2) << 32);
+    }
+}
+
+template <int PIX = 1>
 __device__ __forceinline__ uint64_t frame_base_of(const EncParams &p, uint32_t f, uint32_t inf, uint32_t glob) {
-    const uint64_t meta = 32ull + 2ull * p.T;
+    const uint64_t meta = 32ull + (uint64_t)(1 + PIX) * p.T;
     return p.slot_stride ? (uint64_t)f * p.slot_stride : (uint64_t)f * meta + 8ull * (uint64_t)(uint32_t)(glob - inf);
 }
 
 // Worker-side stores of one finished chunk: the per-tile depth/min bytes of this lane and the
 // wave's contiguous payload range (LDS -> global, 16 B per lane).
-template <bool ALIGNED_OUT>
+template <bool ALIGNED_OUT, int PIX = 1>
 __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkRef &k, uint32_t meta4, uint32_t wbase,
                                                 uint32_t wtot, uint32_t inf, uint32_t glob, const uint64_t *pay,
                                                 int lane, bool swz) {
-    const uint64_t meta = 32ull + 2ull * p.T;
-    uint8_t *fb = p.out + frame_base_of(p, k.f, inf, glob);
+    const uint64_t meta = 32ull + (uint64_t)(1 + PIX) * p.T;
+    uint8_t *fb = p.out + frame_base_of<PIX>(p, k.f, inf, glob);
     uint8_t *depth_arr = fb + 24;
     uint8_t *min_arr = fb + 28 + p.T;
     const uint32_t dA = meta4 & 0xFFu, dB = (meta4 >> 8) & 0xFFu, mnA = (meta4 >> 16) & 0xFFu, mnB = meta4 >> 24;
-    if (ALIGNED_OUT) {   // fb % 8 == 0 and T % 4 == 0: t0 is even, so both arrays are 2-aligned here
+    if (PIX == 2) {   // one tile per lane: meta4 = depth | minimum << 16 (ALIGNED_OUT: fb % 8 == 0, T % 8 == 0 -> U16-aligned minima)
+        if (k.hasA) {
+            depth_arr[k.t0] = (uint8_t)dA;
+            uint8_t *m = min_arr + 2ull * k.t0;
+            if (ALIGNED_OUT) *reinterpret_cast<uint16_t *>(m) = (uint16_t)(meta4 >> 16);
+            else { m[0] = (uint8_t)(meta4 >> 16); m[1] = (uint8_t)(meta4 >> 24); }
+        }
+    } else if (ALIGNED_OUT) {   // fb % 8 == 0 and T % 4 == 0: t0 is even, so both arrays are 2-aligned here
         if (k.hasB) {
             *reinterpret_cast<uint16_t *>(depth_arr + k.t0) = (uint16_t)(dA | (dB << 8));
             *reinterpret_cast<uint16_t *>(min_arr + k.t0) = (uint16_t)(mnA | (mnB << 8));
@@ -627,7 +697,7 @@ __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkR
     }
 }
 
-template <int IN_MODE, bool ALIGNED_OUT>
+template <int IN_MODE, bool ALIGNED_OUT, int PIX = 1>
 __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     __shared__ __attribute__((aligned(16))) EncShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -655,9 +725,9 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         return;
     }
     const uint32_t rank = __builtin_amdgcn_readfirstlane(sh.boot[0]);
-    ChunkRef cur = chunk_ref(p, rank, tid);
+    ChunkRef cur = chunk_ref<PIX>(p, rank, tid);
     uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-    load_chunk<IN_MODE>(p, cur, r0a, r0b);          // in flight while the mode is agreed below
+    load_chunk<IN_MODE, true, PIX>(p, cur, r0a, r0b);          // in flight while the mode is agreed below
     __syncthreads();   // sh.boot is reused below
 
     // How later chunks are claimed.  STATIC (chunk = rank + k*G, no atomics) is only safe when
@@ -692,8 +762,8 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     constexpr uint32_t kTailRounds = 3;
     const uint32_t full_rounds = p.n_chunks / G;
     const uint32_t s_static = full_rounds >= kTailRounds + 2u ? (full_rounds - kTailRounds) * G : 0xFFFFFFFFu;
-    ChunkRef nxt = chunk_ref(p, __builtin_amdgcn_readfirstlane(sh.boot[0]), tid);
-    ChunkRef prev = chunk_ref(p, 0xFFFFFFFFu, tid);
+    ChunkRef nxt = chunk_ref<PIX>(p, __builtin_amdgcn_readfirstlane(sh.boot[0]), tid);
+    ChunkRef prev = chunk_ref<PIX>(p, 0xFFFFFFFFu, tid);
     uint64_t *pay = sh.pay[wave];
     uint32_t prev_meta = 0, prev_wbase = 0, prev_wtot = 0, prev_total = 0;
     bool prev_swz = false;   // prev's payload image is swizzled (its wave was all depth 8)
@@ -753,11 +823,17 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         // ---- statistics of cur (dbde_util.cpp:30-68), offsets inside the wave, AGG ---------------------------
         uint32_t mnA, mxA, mnB, mxB, dA, dB, incl, wtot;
         auto statistics = [&]() __attribute__((always_inline)) {
-            load_fixup_generic<IN_MODE>(p, cur, ca, cb);
-            tile_minmax(ca, mnA, mxA);
-            tile_minmax(cb, mnB, mxB);
-            dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
-            dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
+            if (PIX == 2) {   // one 16-bit tile per lane: "A" is the tile, "B" stays empty
+                tile_minmax16(ca, cb, mnA, mxA);
+                dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
+                mnB = 0u; mxB = 0u; dB = 0u;
+            } else {
+                load_fixup_generic<IN_MODE>(p, cur, ca, cb);
+                tile_minmax(ca, mnA, mxA);
+                tile_minmax(cb, mnB, mxB);
+                dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
+                dB = cur.hasB ? depth_of_range(mxB - mnB) : 0u;
+            }
             incl = wave_scan_incl(dA + dB);
             wtot = __builtin_amdgcn_readlane(incl, 63);
             if (lane == 0) {
@@ -782,19 +858,19 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         // that remains is the in-order prefix itself, not the position of the poll.
 #if DBDE_POLL == 0
         mailbox();
-        load_chunk<IN_MODE>(p, nxt, na, nb);
+        load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
         statistics();
 #elif DBDE_POLL == 1
-        load_chunk<IN_MODE>(p, nxt, na, nb);
+        load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
         statistics();
         mailbox();
 #else
         if (wave == 0) {
             statistics();
             mailbox();
-            load_chunk<IN_MODE>(p, nxt, na, nb);
+            load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
         } else {
-            load_chunk<IN_MODE>(p, nxt, na, nb);
+            load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
             statistics();
         }
 #endif
@@ -827,22 +903,27 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
 
         // ---- 5. prev: LDS -> global; cur: pack over it (wave-private region) -----------------------
         if (prev.valid) {
-            store_wave_part<ALIGNED_OUT>(p, prev, prev_meta, prev_wbase, prev_wtot, inf, glob, pay, lane, prev_swz);
+            store_wave_part<ALIGNED_OUT, PIX>(p, prev, prev_meta, prev_wbase, prev_wtot, inf, glob, pay, lane, prev_swz);
             // what depends only on prefixes -- frame header, the I32 fields, per-frame offset and size -- is
             // written by the workgroup that holds the frame's first / last chunk (one lane, a few stores).  The
             // scanner used to do this; with 64 or fewer chunks per frame it then met a frame boundary in every
             // window of records and its rounds took twice as long (profiles/r02 diag).
             if (tid == 64 * (kEncWaves - 1) && (prev.cf == 0u || prev.cf == p.chunks_per_frame - 1u))
-                write_frame_fields<ALIGNED_OUT>(p, prev.f, prev.cf, inf + prev_total, glob - inf);
+                write_frame_fields<ALIGNED_OUT, PIX>(p, prev.f, prev.cf, inf + prev_total, glob - inf);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // all depth 8: lanes write at a 128-byte stride, the image is swizzled; otherwise the offsets are as irregular
         // as the depths and the swizzle is only address arithmetic (mixed encode 0.68 -> 0.72 without it)
-        const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
+        // (DBDE16: depth 16 in every tile of the wave)
+        const bool all8 = PIX == 2 ? (bool)__builtin_amdgcn_readfirstlane(__all(dA == 16u || !cur.hasA))
+                                   : (bool)__builtin_amdgcn_readfirstlane(__all((dA == 8u || !cur.hasA) && (dB == 8u || !cur.hasB)));
         if (wtot != 0u) {
             const uint32_t offA = incl - (dA + dB), offB = offA + dA;
-            if (all8) {
+            if (PIX == 2) {
+                if (!all8) pack_tile16(ca, cb, mnA, dA, pay, offA, kWaveWords + (uint32_t)lane);
+                else if (cur.hasA) pack_tile16_d16(ca, cb, mnA, pay, offA);
+            } else if (all8) {
                 if (cur.hasA) pack_tile_d8(ca, mnA, pay, offA);
                 if (cur.hasB) pack_tile_d8(cb, mnB, pay, offB);
             } else {
@@ -855,13 +936,13 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
 
         // ---- rotate the pipeline -------------------------------------------------------------------
         prev = cur;
-        prev_meta = dA | (dB << 8) | (mnA << 16) | (mnB << 24);
+        prev_meta = PIX == 2 ? dA | (mnA << 16) : dA | (dB << 8) | (mnA << 16) | (mnB << 24);
         prev_wbase = wbase;
         prev_wtot = wtot;
         prev_swz = all8 || DBDE_ENC_SWZ_ALL;
         prev_total = cur_total;
         cur = nxt;
-        nxt = chunk_ref(p, lb_ok ? next_id : 0xFFFFFFFFu, tid);
+        nxt = chunk_ref<PIX>(p, lb_ok ? next_id : 0xFFFFFFFFu, tid);
     };
 #ifdef DBDE_DIAG
     uint32_t dg_pair = 0;
@@ -896,6 +977,16 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
 }
 
 static int in_mode_of(const EncParams &p, bool fast_in) { return fast_in ? kInFast : (p.lanes_per_row ? kInRaw : kInBytes); }
+
+// DBDE16 through the same persistent kernel (PIX = 2): W % 8 == 0 and a 16-byte aligned base, 512 tiles per chunk,
+// EncParams::frame_pixels in BYTES.  Other geometries and small launches stay with dbde16_kernels.hip.
+hipError_t launch_encode16_fast(const EncParams &p, bool aligned_out, hipStream_t s) {
+    dim3 block(kEncThreads);
+    dim3 grid(p.n_chunks + 1u < p.grid_blocks ? p.n_chunks + 1u : p.grid_blocks);
+    if (aligned_out) hipLaunchKernelGGL((encode_kernel<kInFast, true, 2>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((encode_kernel<kInFast, false, 2>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
     dim3 block(kEncThreads);

@@ -17,6 +17,10 @@ mask = (torch.ones_like(dd) << dd) - 1
 noise = torch.randint(0, 65536, (n, H, W), device="cuda", generator=g) & mask
 base = torch.randint(0, 32768, (n, H // 8, W // 8), device="cuda", generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
 imgs = torch.minimum(base, 65535 - mask).add_(noise).to(torch.int32).to(torch.int16).contiguous()   # two's complement bits = the U16 pixels
+if "full" in sys.argv:    # every tile of depth 16 (worst case: payload = raw)
+    imgs = torch.randint(-32768, 32768, (n, H, W), device="cuda", generator=g, dtype=torch.int16)
+if "d12" in sys.argv:     # 12-bit sensor noise in 16-bit pixels: every tile of depth 12
+    imgs = torch.randint(0, 4096, (n, H, W), device="cuda", generator=g, dtype=torch.int16)
 del d, dd, mask, noise, base
 maxf = int(codec.L.dbde16_hip_max_frame_bytes(W, H))
 slot = ((maxf + 255) // 256) * 256 if SLOTS else 0

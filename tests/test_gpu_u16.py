@@ -81,17 +81,20 @@ def test_full_size_round_trip_and_spot_check(codec, o16):
     assert buf[32 + int(o[3]): 32 + int(o[3] + s[3])].cpu().numpy().tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("force_tickets", [False, True])
+@pytest.mark.parametrize("flags", [0, 1, 32, 33])
 @pytest.mark.parametrize("kind", ["mixed", "full"])
-def test_more_chunks_than_resident_workgroups(o16, kind, force_tickets):
-    """Launches whose chunks outnumber the resident workgroups: the persistent encoder claims chunk ids by static
-    strides once all workgroups have arrived, or by tickets (forced here through DBDE_HIP_EXPERIMENT bit 0);
-    `full` content (every tile of depth 16) also takes the path of chunks larger than the LDS payload image."""
+def test_more_chunks_than_resident_workgroups(o16, kind, flags):
+    """Launches whose chunks outnumber the resident workgroups.  Rows of 16-byte aligned pixels go through the 8-bit
+    path's persistent encoder (encode_kernel<.., PIX = 2>); DBDE_HIP_EXPERIMENT bit 5 keeps them on enc16_kernel, the
+    kernel of every other geometry.  Both claim chunk ids by static strides once all workgroups have arrived, or by
+    tickets (forced through bit 0); `full` content (every tile of depth 16) also takes enc16_kernel's path of chunks
+    larger than the LDS payload image."""
     import os
     import torch
     import dbde_video_cpp_amd as dv
-    if force_tickets:
-        os.environ["DBDE_HIP_EXPERIMENT"] = "1"
+    force_tickets = flags
+    if flags:
+        os.environ["DBDE_HIP_EXPERIMENT"] = str(flags)
     try:
         c2 = dv.Codec(0)
     finally:
@@ -109,13 +112,48 @@ def test_more_chunks_than_resident_workgroups(o16, kind, force_tickets):
                 offs, sizes = c2.encode_frames16(imgs, W, H, n, buf, 32, cap, slot_stride=slot)
                 back, res = c2.decode_frames16(buf, 32, cap, offs, W, H, n)
                 c2.sync()
-                assert torch.equal(back, imgs), (kind, force_tickets, slot, rep)
+                assert torch.equal(back, imgs), (kind, flags, slot, rep)
             o, s = offs.cpu().numpy(), sizes.cpu().numpy()
             for f in (0, 7, 15):
                 want = pack16(o16, imgs_h[f], f)
                 assert buf[32 + int(o[f]): 32 + int(o[f] + s[f])].cpu().numpy().tobytes() == want.tobytes(), (kind, slot, f)
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("W,H,n,off", [(1000, 1003, 40, 32), (1000, 1003, 40, 33), (1024, 768, 64, 40), (8, 8, 600 * 512, 32),
+                                       (4096, 3072, 3, 32), (1001, 1003, 40, 32)])
+@pytest.mark.parametrize("kind", ["mixed", "full", "small"])
+def test_persistent_encoder_geometries(codec, o16, W, H, n, off, kind):
+    """The PIX = 2 instance of the persistent encoder: a last tile row that is padded (H % 8), tile counts that leave
+    the U16 minima and the payload unaligned (T % 8, odd output offsets), one-tile frames (every chunk nearly
+    empty), frames of many chunks; 1001 wide stays on enc16_kernel.  Every frame byte for byte against the oracle
+    at small n, a sample of frames otherwise."""
+    import torch
+    rng = np.random.default_rng(W + 3 * H + n + off + len(kind))
+    if n > 1000:   # many one-tile frames: a few distinct ones, repeated
+        base = make_images(rng, 997, W, H, kind)
+        imgs_h = np.ascontiguousarray(base[np.arange(n) % 997])
+    else:
+        imgs_h = make_images(rng, n, W, H, kind)
+    imgs = torch.from_numpy(imgs_h.view(np.int16)).cuda()
+    maxf = int(codec.L.dbde16_hip_max_frame_bytes(W, H))
+    for slot in (0, ((maxf + 255) // 256) * 256, maxf + 3):
+        cap = (n - 1) * slot + maxf if slot else n * maxf
+        buf = torch.full((off + cap + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, off, cap, first_index=5, slot_stride=slot)
+        back, res = codec.decode_frames16(buf, off, cap, offs, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs), (W, H, kind, slot)
+        host, o, s = buf.cpu().numpy(), offs.cpu().numpy(), sizes.cpu().numpy()
+        sample = range(n) if n <= 64 else list(range(0, n, max(1, n // 61))) + [n - 1]
+        for f in sample:
+            want = pack16(o16, imgs_h[f], 5 + f)
+            got = host[off + int(o[f]): off + int(o[f] + s[f])]
+            assert int(s[f]) == len(want) and got.tobytes() == want.tobytes(), (W, H, kind, slot, f)
+        if slot == 0:
+            assert o[0] == 0 and (o[1:] == np.cumsum(s)[:-1]).all()
+            assert (host[off + int(o[-1] + s[-1]):-64] == 0xEE).all() and (host[:off] == 0xEE).all()
 
 
 def test_malformed_frames_are_rejected(codec, o16):

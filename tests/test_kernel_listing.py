@@ -72,13 +72,15 @@ def pixel_load_groups(lines):
     return out
 
 
-PERSISTENT = ["_ZN4dbde13encode_kernelILi0ELb1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0EEEvNS_9EncParamsE",
-              "_ZN4dbde13encode_kernelILi1ELb1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi1ELb0EEEvNS_9EncParamsE"]
+PERSISTENT = ["_ZN4dbde13encode_kernelILi0ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0ELi1EEEvNS_9EncParamsE",
+              "_ZN4dbde13encode_kernelILi1ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi1ELb0ELi1EEEvNS_9EncParamsE",
+              # DBDE16 through the same kernel (PIX = 2: one 16-bit tile per lane, the same eight 16-byte loads per step)
+              "_ZN4dbde13encode_kernelILi0ELb1ELi2EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0ELi2EEEvNS_9EncParamsE"]
 
 
 @pytest.mark.parametrize("mangled", PERSISTENT)
 def test_persistent_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing, mangled):
-    """Aligned widths (encode_kernel<0,*>) and any geometry (<1,*>: BASELINE configs[3]'s kernel)."""
+    """Aligned widths (encode_kernel<0,*,1>), any geometry (<1,*,1>: BASELINE configs[3]'s kernel), DBDE16 (<0,*,2>)."""
     lines = function_body(listing, mangled)
     groups = pixel_load_groups(lines)
     steady = [(a, b, w) for a, b, w in groups if w]   # the prologue's group meets a barrier first (drained behind it)

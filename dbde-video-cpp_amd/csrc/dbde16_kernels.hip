@@ -337,13 +337,20 @@ __global__ __launch_bounds__(kChunkTiles16, DBDE16_WAVES) void enc16_kernel(Para
 
 // ---- decode ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kChunkTiles16 * 128 + 48];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kChunkTiles16 * 128 + 256 + 48];   // + the shift, rounded up to a swizzle group
     __shared__ uint32_t s_tot[kChunkTiles16 / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 #ifdef DBDE_DIAG
     uint64_t dt[5]; dt[0] = wall_clock64();
 #endif
-    const uint32_t c = blockIdx.x, f = c / p.chunks_per_frame, cf = c - f * p.chunks_per_frame;
+    // workgroup -> chunk as in the 8-bit decoder: inside a group of 128 chunks each XCD (workgroup id mod 8) takes 16
+    // CONSECUTIVE chunks, so that an XCD's L2 sees runs of the stream and of the image instead of every eighth 32 KB
+    uint32_t c = blockIdx.x;
+    {
+        const uint32_t grp = c / 128u, rem = c % 128u;
+        if ((grp + 1u) * 128u <= gridDim.x) c = grp * 128u + (rem & 7u) * 16u + (rem >> 3);
+    }
+    const uint32_t f = c / p.chunks_per_frame, cf = c - f * p.chunks_per_frame;
     // the three index words are requested together (one memory round trip, not three), then looked at
     const uint32_t *co = p.chunk_off + (size_t)f * (p.chunks_per_frame + 1u) + cf;
     const uint32_t ok = p.frame_ok[f], w_begin = co[0], w_end = co[1];
@@ -360,6 +367,12 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
     const uint8_t *asrc = src - shift;
     const uint32_t n16 = (shift + 8u * words + 15u) >> 4;
+    // Every tile of depth 16 (the chunk's word count says so): lanes read the image at a 128-byte stride, which piles
+    // onto two banks; the image is then held swizzled -- physical 16-byte slot i = logical slot i ^ ((i >> 4) & 15),
+    // a permutation inside 256-byte groups, applied on the SOURCE side of the DMA -- as in the 8-bit decoder.
+    const uint32_t n_tiles = p.T - cf * kChunkTiles16 < kChunkTiles16 ? p.T - cf * kChunkTiles16 : kChunkTiles16;
+    const bool swz = words != 0u && words == 16u * n_tiles && (shift & 7u) == 0u;
+    const uint32_t n16r = swz ? (n16 + 15u) & ~15u : n16;
     uint32_t d = 0, mn = 0;   // this lane's tile: depth and minimum, in flight with the payload
     if (has) {
         d = fb[24 + t];
@@ -370,18 +383,17 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     // shift) are in flight before the first is stored, one memory round trip for the chunk
     const uint64_t room = (uint64_t)((p.stream + p.stream_bytes) - asrc);
     const uint32_t n16_in = room / 16u < (uint64_t)n16 ? (uint32_t)(room / 16u) : n16;
-    {
-        constexpr int kMaxPieces = (kChunkTiles16 * 128 + 16 + 16 * kChunkTiles16 - 1) / (16 * kChunkTiles16);   // 9: the shift may add one
-        u32x4_t q[kMaxPieces];
+    {   // LDS-DMA (global_load_lds_dwordx4): the wave's 64 pieces land at wave-uniform base + lane * 16, no staging
+        // registers; all of a thread's pieces (at most 9: 256 tiles x 128 bytes + the shift) are in flight together
+        constexpr int kMaxPieces = (kChunkTiles16 * 128 + 16 + 16 * kChunkTiles16 - 1) / (16 * kChunkTiles16);
 #pragma unroll
         for (int j = 0; j < kMaxPieces; j++) {
             const uint32_t i = tid + (uint32_t)j * kChunkTiles16;
-            if (i < n16_in) q[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(asrc + 16ull * i));
-        }
-#pragma unroll
-        for (int j = 0; j < kMaxPieces; j++) {
-            const uint32_t i = tid + (uint32_t)j * kChunkTiles16;
-            if (i < n16_in) *reinterpret_cast<u32x4_t *>(s_in + 16u * i) = q[j];
+            const uint32_t src_slot = swz ? i ^ ((i >> 4) & 15u) : i;
+            if (i < n16r && src_slot < n16_in)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + 16ull * src_slot),
+                                                 (__attribute__((address_space(3))) void *)(s_in + 16u * ((uint32_t)j * kChunkTiles16 + wave * 64u)),
+                                                 16, 0, 2);
         }
     }
     for (uint32_t i = n16_in + tid; i < n16; i += kChunkTiles16) {   // a piece that would cross the end of the extent: byte by byte
@@ -391,11 +403,13 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
             if (s1 < p.stream + p.stream_bytes) wq[b >> 2] |= (uint32_t)*s1 << (8u * (b & 3u));
         }
         u32x4_t q = {wq[0], wq[1], wq[2], wq[3]};
-        *reinterpret_cast<u32x4_t *>(s_in + 16u * i) = q;
+        *reinterpret_cast<u32x4_t *>(s_in + 16u * (swz ? i ^ ((i >> 4) & 15u) : i)) = q;
     }
     const uint32_t incl = wave_scan_incl(d);
     if (lane == 63u) s_tot[wave] = incl;
     DIAG_MARK(1);
+    // a barrier does not drain vector memory: every wave sees its own DMA land (and its LDS writes retire) first
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     DIAG_MARK(2);
     uint32_t wbase = 0;
@@ -403,12 +417,91 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
     if (!has) return;
     const uint32_t byte0 = shift + 8u * (wbase + incl - d);
     const uint32_t ty = t / p.w, tx = t - ty * p.w;
-    const int x0 = 8 * (int)tx;
+    const int x0t = 8 * (int)tx;
     const uint64_t fmask = d >= 16u ? 0xFFFFull : ((1ull << d) - 1ull);
     uint16_t *img = p.images + (size_t)f * p.frame_pixels;
+    const bool rows16 = (p.W & 7) == 0 && (reinterpret_cast<uintptr_t>(p.images) & 15u) == 0u;   // every tile row a 16-byte aligned store
     // A row's 8*d bits start at byte r*d of the tile payload: two 64-bit windows, one per 4-pixel half (the second
-    // starts 4*d bits = d/2 bytes, and 4 bits when d is odd, later).  LDS takes 8-byte reads at any byte address
-    // (profiles/lds_unaligned_probe.hip); all sixteen are requested before the first is used.
+    // starts 4*d bits = d/2 bytes, and 4 bits when d is odd, later).
+#ifndef DBDE16_ALIGNED_READS
+#define DBDE16_ALIGNED_READS 1   // A/B switch: 0 = two unaligned ds_read_b64 per row and 64-bit shifts per pixel
+#endif
+    if (swz) {   // depth 16 everywhere, rows 8-byte aligned: a row is its sixteen bytes plus the minimum
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const uint32_t mn2 = mn * 0x00010001u;
+        uint2 lo8[8], hi8[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t A = byte0 + 16u * (uint32_t)r, B = A + 8u;
+            lo8[r] = *reinterpret_cast<const uint2 *>(s_in + (A ^ ((A >> 4) & 0xF0u)));
+            hi8[r] = *reinterpret_cast<const uint2 *>(s_in + (B ^ ((B >> 4) & 0xF0u)));
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            auto add = [&](uint32_t x) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, x) + __builtin_bit_cast(u16x2, mn2)); };
+            const u32x4_t o = {add(lo8[r].x), add(lo8[r].y), add(hi8[r].x), add(hi8[r].y)};
+            const int yy = 8 * (int)ty + r;
+            if (yy < p.H) {
+                uint16_t *row = img + (size_t)yy * (size_t)p.W + x0t;
+                if (x0t + 8 <= p.W) {
+                    if (rows16) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(row));
+                    else __builtin_nontemporal_store(o, reinterpret_cast<u32x4_unaligned *>(row));
+                } else {
+                    for (int i = 0; i < 8; i++) if (x0t + i < p.W) row[i] = (uint16_t)(o[i >> 1] >> (16 * (i & 1)));
+                }
+            }
+        }
+        return;
+    }
+#if DBDE16_ALIGNED_READS
+    // Each window comes out of the three ALIGNED dwords that hold it (v_alignbyte, as in the 8-bit decoder: LDS reads
+    // of 8 bytes at odd addresses are what made mixed depths the slow content here); a pixel is v_alignbit at i*d
+    // (shift counts are taken modulo 32: from 32 on the window's high dword is shifted instead), two pixels per dword,
+    // the minimum added with v_pk_add_u16 (modulo 2^16, as the spec says).
+    uint32_t lw[8][3], hw[8][3];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t a = byte0 + (uint32_t)r * d, ah = a + (d >> 1);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(s_in + (a & ~3u));
+        const uint32_t *qh = reinterpret_cast<const uint32_t *>(s_in + (ah & ~3u));
+        lw[r][0] = q[0]; lw[r][1] = q[1]; lw[r][2] = q[2];
+        hw[r][0] = qh[0]; hw[r][1] = qh[1]; hw[r][2] = qh[2];
+    }
+    DIAG_MARK(3);
+    const uint32_t m32 = (uint32_t)fmask, mn2 = mn * 0x00010001u, sh_odd = (d & 1u) * 4u;
+    const bool c2 = 2u * d >= 32u, c3 = 3u * d >= 32u;
+    auto four = [&](uint32_t x0, uint32_t x1, uint32_t &o0, uint32_t &o1) __attribute__((always_inline)) {
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const uint32_t p0 = x0 & m32;
+        const uint32_t p1 = __builtin_amdgcn_alignbit(x1, x0, d) & m32;
+        const uint32_t p2 = __builtin_amdgcn_alignbit(c2 ? 0u : x1, c2 ? x1 : x0, 2u * d) & m32;
+        const uint32_t p3 = __builtin_amdgcn_alignbit(c3 ? 0u : x1, c3 ? x1 : x0, 3u * d) & m32;
+        o0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, p0 | (p1 << 16)) + __builtin_bit_cast(u16x2, mn2));
+        o1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, p2 | (p3 << 16)) + __builtin_bit_cast(u16x2, mn2));
+    };
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t a = byte0 + (uint32_t)r * d, ah = a + (d >> 1);
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(lw[r][1], lw[r][0], a), x1 = __builtin_amdgcn_alignbyte(lw[r][2], lw[r][1], a);
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(hw[r][1], hw[r][0], ah), w1 = __builtin_amdgcn_alignbyte(hw[r][2], hw[r][1], ah);
+        const uint32_t h0 = __builtin_amdgcn_alignbit(w1, w0, sh_odd), h1 = w1 >> sh_odd;
+        uint32_t o0, o1, o2, o3;
+        four(x0, x1, o0, o1);
+        four(h0, h1, o2, o3);
+        const u32x4_t o = {o0, o1, o2, o3};
+        const int yy = 8 * (int)ty + r;
+        if (yy < p.H) {
+            uint16_t *row = img + (size_t)yy * (size_t)p.W + x0t;
+            if (x0t + 8 <= p.W) {
+                // written once, read by nobody here: non-temporal, as in the 8-bit decoder
+                if (rows16) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(row));
+                else __builtin_nontemporal_store(o, reinterpret_cast<u32x4_unaligned *>(row));
+            } else {
+                for (int i = 0; i < 8; i++) if (x0t + i < p.W) row[i] = (uint16_t)(o[i >> 1] >> (16 * (i & 1)));
+            }
+        }
+    }
+#else
     uint64_t lo[8], hi[8];
     {
         const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)s_in + byte0;
@@ -431,16 +524,18 @@ __global__ __launch_bounds__(kChunkTiles16) void dec16_kernel(DecParams16 p) {
         }
         const int yy = 8 * (int)ty + r;
         if (yy < p.H) {
-            uint16_t *row = img + (size_t)yy * (size_t)p.W + x0;
-            if (x0 + 8 <= p.W) {
+            uint16_t *row = img + (size_t)yy * (size_t)p.W + x0t;
+            if (x0t + 8 <= p.W) {
                 u32x4_t o;
                 o[0] = px[0] | (px[1] << 16); o[1] = px[2] | (px[3] << 16); o[2] = px[4] | (px[5] << 16); o[3] = px[6] | (px[7] << 16);
-                *reinterpret_cast<u32x4_unaligned *>(row) = o;
+                if (rows16) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(row));
+                else __builtin_nontemporal_store(o, reinterpret_cast<u32x4_unaligned *>(row));
             } else {
-                for (int i = 0; i < 8; i++) if (x0 + i < p.W) row[i] = (uint16_t)px[i];
+                for (int i = 0; i < 8; i++) if (x0t + i < p.W) row[i] = (uint16_t)px[i];
             }
         }
     }
+#endif
 #ifdef DBDE_DIAG
     if (tid == 0 && (c & 63u) == 5u) {   // a sample of workgroups: fetch issue | barrier | LDS reads | unpack + stores (issue)
         DIAG_MARK(4);

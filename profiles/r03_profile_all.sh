@@ -5,3 +5,4 @@ bash profiles/run_profile.sh $T 2 noise8
 bash profiles/run_profile.sh $T 2 mixed
 bash profiles/run_profile.sh $T 3 mixed
 bash profiles/run_profile.sh $T 4 mixed
+bash profiles/run_profile_u16.sh $T

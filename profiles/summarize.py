@@ -31,9 +31,15 @@ def main():
     dur = defaultdict(list)
     for r in kt:
         dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    out.append("== kernel trace (rocprofv3 --kernel-trace): name, calls, avg us, min us, max us, total us")
+    out.append("== kernel trace (rocprofv3 --kernel-trace): name, calls, avg us, min us, max us, total us, "
+               "avg us of the timed steps (the first 2 dispatches = bench.py's warm-up dropped; '-' below 6 calls)")
+    start = defaultdict(list)
+    for r in kt:
+        start[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        out.append(f"{k[:90]:90s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e3:12.1f}")
+        timed = [x[1] for x in sorted(start[k])[2:]] if len(v) >= 6 else []
+        steady = f"{sum(timed)/len(timed)/1e3:10.2f}" if timed else "         -"
+        out.append(f"{k[:90]:90s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e3:12.1f} {steady}")
     # 2/3/4 counters: per kernel averages
     traffic = {}
     for sub in ("fetch", "write", "sq"):

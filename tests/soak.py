@@ -72,8 +72,9 @@ o16.dbde16_oracle_pack_frame.restype = C.c_size_t
 o16.dbde16_oracle_pack_frame.argtypes = [C.c_uint64, u16p, C.c_int, C.c_int, u8p]
 u16_rounds = max(a.rounds // 4, 1)
 for r in range(u16_rounds):
-    W, H = [(2048, 1536), (1921, 1081), (4096, 3072), (640, 480)][int(rng.integers(0, 4))]
-    n = int(rng.choice([1, 3, 16, 40]))
+    # (aligned widths with enough chunks take the persistent encoder, PIX = 2; 1000x1003: T % 8 != 0, unaligned minima)
+    W, H = [(2048, 1536), (1921, 1081), (4096, 3072), (640, 480), (1000, 1003), (1024, 768)][int(rng.integers(0, 6))]
+    n = int(rng.choice([1, 3, 16, 40, 64]))
     kind = str(rng.choice(["full", "mixed", "small"]))
     d = rng.integers(0, 17, size=(n, (H + 7) // 8, (W + 7) // 8))
     dd = np.repeat(np.repeat(d, 8, axis=1), 8, axis=2)[:, :H, :W]

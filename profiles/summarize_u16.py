@@ -22,7 +22,7 @@ for c in ("mixed", "full", "d12"):
     for r in rows:
         dur[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     out.append(f"== {c}: {n} frames of {W}x{H} U16, packed/raw {ratio}, algorithmic bytes per launch {alg/1e9:.3f} GB")
-    out.append("   " + log.strip().splitlines()[-1])
+    out.append("   " + [ln for ln in log.splitlines() if ln.startswith("DBDE16 ")][-1])
     out.append("   kernel, calls, avg us, min us, avg us without the first 2 (warm-up), fraction of 8 TB/s on that average")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
         if "dbde" not in k:

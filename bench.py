@@ -319,6 +319,47 @@ class Bench:
         del imgs, buf, out
         return r
 
+    def case16(self, W=4096, H=3072, n=128, steps=10):
+        """DBDE16 (the higher-bit-depth extension of SURVEY 8f rank 4; parity unpinned: the reference defines no such
+        format): n frames of U16 pixels, per-tile depth uniform in 0..16, encode + decode per step, round trip checked
+        for identity.  Reported beside the headline, never part of `value`."""
+        torch, codec = self.torch, self.codec
+        progress(f"DBDE16 {W}x{H} x{n}: {steps} steps")
+        g = torch.Generator(device="cuda").manual_seed(SEED & 0x7FFFFFFF)
+        d = torch.randint(0, 17, (n, H // 8, W // 8), device="cuda", generator=g, dtype=torch.int32)
+        dd = d.repeat_interleave(8, 1).repeat_interleave(8, 2)
+        mask = (torch.ones_like(dd) << dd) - 1
+        noise = torch.randint(0, 65536, (n, H, W), device="cuda", generator=g, dtype=torch.int32) & mask
+        base = torch.randint(0, 32768, (n, H // 8, W // 8), device="cuda", generator=g, dtype=torch.int32).repeat_interleave(8, 1).repeat_interleave(8, 2)
+        imgs = torch.minimum(base, 65535 - mask).add_(noise).to(torch.int16).contiguous()   # two's complement bits = the U16 pixels
+        del d, dd, mask, noise, base
+        cap = n * int(codec.L.dbde16_hip_max_frame_bytes(W, H))
+        buf = torch.empty(32 + cap + 64, dtype=torch.uint8, device="cuda")
+        out = torch.empty_like(imgs)
+        for _ in range(2):
+            offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap)
+            codec.decode_frames16(buf, 32, cap, offs, W, H, n, images=out)
+        codec.sync()
+        identical = bool(torch.equal(out, imgs))
+        packed = int(sizes.sum().item())
+        codec.timing(True)
+        codec.timing_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap)
+            codec.decode_frames16(buf, 32, cap, offs, W, H, n, images=out)
+        codec.sync()
+        dt = (time.perf_counter() - t0) / steps
+        tk = codec.timing_read()
+        codec.timing(False)
+        raw = n * W * H * 2
+        enc, dec = tk["encode"][0] / steps, tk["decode"][0] / steps
+        return {"workload": f"{n} frames of {W}x{H} U16, per-tile depth uniform in 0..16, concatenated", "parity": "unpinned (extension)",
+                "frames_per_s": round(n / dt, 1), "packed_over_raw": round(packed / raw, 4), "identical": identical,
+                "encode": {"ms": round(enc, 4), "frac": round((raw + packed) / enc / 1e6 / HBM_PEAK_GBPS, 4)},
+                "decode": {"ms": round(dec, 4), "frac": round((raw + packed) / dec / 1e6 / HBM_PEAK_GBPS, 4),
+                           "index_ms": round(tk["decode_index"][0] / steps, 4)}}
+
     def single_frame(self, W, H, content, reps=300):
         """configs[1] literally: ONE frame per encode+decode call, device-resident, back to back."""
         torch, dv, codec = self.torch, self.dv, self.codec
@@ -632,6 +673,11 @@ def main():
                         if mode == "nccl" or gather_mode != "native":
                             line["gather"] = {"error": line["gather_errors"][-1]}
                             gather_failed = True
+        if rank == 0 and world == 1 and not args.only:
+            try:
+                line["dbde16"] = b.case16()
+            except Exception as e:   # an extension: reported, never fatal to the line
+                line["dbde16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0 and world == 1 and not args.no_single and not args.only:
             line["single_frame"] = b.single_frame(4096, 3072, "noise8")
             line["single_frame"]["mixed_us_per_round_trip"] = b.single_frame(4096, 3072, "mixed")["us_per_round_trip"]

@@ -249,6 +249,38 @@ size_t dbde_hip_image_bytes(int W, int H, uint64_t n64) {
     return 12 + 2 * (size_t)g.T + 8 * (size_t)n64;
 }
 
+// What every launch of the persistent / small / tiny encoders is told about the batch (`pix` bytes per pixel: 1 = DBDE,
+// 2 = DBDE16 through the same kernel; ctrl / state are attached by the caller once the workspace is known).
+static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, int n_frames, uint32_t pix, uint32_t chunks_per_frame,
+                            uint32_t lanes_per_row, const uint8_t *d_images, uint8_t *d_out, uint64_t slot_stride,
+                            uint64_t first_index, uint64_t *d_frame_offsets, uint64_t *d_frame_bytes) {
+    EncParams p;
+    p.images = d_images;
+    p.out = d_out;
+    p.frame_offsets = d_frame_offsets;
+    p.frame_bytes = d_frame_bytes;
+    p.indices = nullptr;
+    p.elapsed_ns = nullptr;
+    p.first_index = first_index;
+    p.state = nullptr;
+    p.ctrl = nullptr;
+    p.sticky = ctx->sticky;
+    p.slot_stride = slot_stride;
+    p.frame_pixels = (uint64_t)pix * g.pixels;   // bytes of one frame's image
+    p.W = W; p.H = H; p.w = g.w; p.h = g.h; p.T = g.T;
+    p.chunks_per_frame = chunks_per_frame;
+    p.n_chunks = (uint32_t)n_frames * chunks_per_frame;
+    p.lanes_per_row = lanes_per_row;
+    p.magic_w = div_magic_of(g.w);
+    p.magic_cpf = div_magic_of(chunks_per_frame);
+    p.magic_lpr = div_magic_of(lanes_per_row);
+    p.last_frame = (uint32_t)n_frames - 1u;
+    p.flags = ctx->exp_flags;
+    p.grid_blocks = ctx->enc_grid;
+    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
+    return p;
+}
+
 // ---- batch encode ----------------------------------------------------------------------------
 
 int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, int H, int n_frames,
@@ -289,32 +321,10 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     const uint32_t n_chunks = (uint32_t)n_chunks64;
-    EncParams p;
-    p.images = d_images;
-    p.out = d_out;
-    p.frame_offsets = d_frame_offsets;
-    p.frame_bytes = d_frame_bytes;
+    EncParams p = enc_params(ctx, g, W, H, n_frames, 1u, enc_cpf, lanes_per_row, d_images, d_out, slot_stride, first_index,
+                             d_frame_offsets, d_frame_bytes);
     p.indices = d_indices;
     p.elapsed_ns = d_elapsed_ns;
-    p.first_index = first_index;
-    p.sticky = ctx->sticky;
-    p.slot_stride = slot_stride;
-    p.frame_pixels = g.pixels;
-    p.W = W;
-    p.H = H;
-    p.w = g.w;
-    p.h = g.h;
-    p.T = g.T;
-    p.chunks_per_frame = enc_cpf;
-    p.lanes_per_row = lanes_per_row;
-    p.magic_w = div_magic_of(g.w);
-    p.magic_cpf = div_magic_of(enc_cpf);
-    p.magic_lpr = div_magic_of(lanes_per_row);
-    p.last_frame = (uint32_t)n_frames - 1u;
-    p.n_chunks = n_chunks;
-    p.flags = ctx->exp_flags;
-    p.grid_blocks = ctx->enc_grid;
-    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
 
     if (g.T <= 64u && slot_stride != 0) {   // tiny frames in slots: several frames per wave, nothing shared (encode_tiny_kernel)
         span_begin(ctx, 0);
@@ -627,28 +637,8 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
         const bool fits = 16ull * g.T < (1ull << 30) && (slot_stride != 0 || (uint64_t)n_frames * 16ull * g.T < (1ull << 32));
         if (W % 8 == 0 && (reinterpret_cast<uintptr_t>(d_images) & 15u) == 0 && fits && n_chunks64 >= ctx->enc_grid &&
             n_chunks64 < (1ull << 31) && !(ctx->exp_flags & 32u)) {
-            EncParams q;
-            q.images = reinterpret_cast<const uint8_t *>(d_images);
-            q.out = d_out;
-            q.frame_offsets = d_frame_offsets;
-            q.frame_bytes = d_frame_bytes;
-            q.indices = nullptr;
-            q.elapsed_ns = nullptr;
-            q.first_index = first_index;
-            q.sticky = ctx->sticky;
-            q.slot_stride = slot_stride;
-            q.frame_pixels = 2ull * g.pixels;   // bytes
-            q.W = W; q.H = H; q.w = g.w; q.h = g.h; q.T = g.T;
-            q.chunks_per_frame = cpf2;
-            q.lanes_per_row = 0;
-            q.magic_w = div_magic_of(g.w);
-            q.magic_cpf = div_magic_of(cpf2);
-            q.magic_lpr = div_magic_of(0);
-            q.last_frame = (uint32_t)n_frames - 1u;
-            q.n_chunks = (uint32_t)n_chunks64;
-            q.flags = ctx->exp_flags;
-            q.grid_blocks = ctx->enc_grid;
-            q.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
+            EncParams q = enc_params(ctx, g, W, H, n_frames, 2u, cpf2, 0u, reinterpret_cast<const uint8_t *>(d_images), d_out,
+                                     slot_stride, first_index, d_frame_offsets, d_frame_bytes);
             const size_t lb_need = (16 + 8 * (size_t)q.n_chunks + 15) & ~(size_t)15;
             const size_t had = ctx->lb_bytes;
             int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);

@@ -51,7 +51,8 @@ struct dbde_hip_ctx {
     // DBDE16 encode workspace (per-tile depth / minimum, chunk and frame totals, frame bases, arrival counter)
     uint8_t *w16 = nullptr;
     size_t w16_bytes = 0;
-    bool lb_clean = false;           // records and counters are all zero (small launches leave them so)
+    bool lb_fresh = true;            // the block holds arbitrary bits (fresh allocation): a small launch zeroes it before its first use
+    uint32_t enc_epoch = 0;          // tag of the last small encode launch's records (launch_encode_small)
     // decode workspace
     uint32_t *chunk_off = nullptr;
     size_t chunk_off_n = 0;
@@ -224,7 +225,6 @@ int dbde_hip_sync(dbde_hip_ctx *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (flag) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->sticky, 0, 4, ctx->stream));
-        ctx->lb_clean = false;   // a kernel gave up: its records may be left behind
         return fail(ctx, DBDE_HIP_ERR_DEVICE, "encode kernel: chunk look-back timed out");
     }
     return DBDE_HIP_OK;
@@ -278,6 +278,7 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
     p.flags = ctx->exp_flags;
     p.grid_blocks = ctx->enc_grid;
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
+    p.small_epoch = 0;
     return p;
 }
 
@@ -338,16 +339,23 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         const size_t had = ctx->lb_bytes;
         int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);
         if (rc) return rc;
-        if (ctx->lb_bytes != had) ctx->lb_clean = false;
+        if (ctx->lb_bytes != had) ctx->lb_fresh = true;
     }
-    // small launches (one frame per call above all): one workgroup per chunk, self-cleaning workspace, no memset
+    // small launches (one frame per call above all): one workgroup per chunk, epoch-tagged records, no memset
     const bool small = n_chunks < ctx->enc_grid;
     span_begin(ctx, 0);
-    // A large launch clears what it is about to use; the whole block (the high-water mark of every launch so far) is
-    // cleared only when a small launch finds it dirty.  Small launches leave what they used clean.
+    // A large launch clears what it is about to use (its records are zero / AGG / INC: bits 63:62, which no epoch has).
+    // A small launch tags its records with its epoch and clears nothing -- except once per block, whose first bits are
+    // arbitrary, and when the epoch counter wraps.
     if (!small) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
-    else if (!ctx->lb_clean) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
-    ctx->lb_clean = small;
+    else {
+        if (ctx->lb_fresh || ctx->enc_epoch >= (1u << 30) - 1u) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
+            ctx->lb_fresh = false;
+            ctx->enc_epoch = 0;
+        }
+        p.small_epoch = ++ctx->enc_epoch;
+    }
 
     p.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
     p.state = reinterpret_cast<unsigned long long *>(ctx->lb + 16);
@@ -485,6 +493,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     p.fuse_rec = ctx->fuse_rec;
     p.fuse_epoch = ctx->fuse_epoch;
     p.fuse_flags = (ctx->exp_flags & 16u) ? 1u : 0u;
+    p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     p.geom = dg;
     span_begin(ctx, 2);
     HIP_TRY(ctx, launch_decode(p, img_mode, self_index ? 1 : (fused ? 2 : 0), ctx->stream));
@@ -643,11 +652,10 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
             const size_t had = ctx->lb_bytes;
             int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);
             if (rc) return rc;
-            if (ctx->lb_bytes != had) ctx->lb_clean = false;
+            if (ctx->lb_bytes != had) ctx->lb_fresh = true;
             const bool aligned_out = (reinterpret_cast<uintptr_t>(d_out) & 7u) == 0 && g.T % 8 == 0 && slot_stride % 8 == 0;
             span_begin(ctx, 0);
             HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
-            ctx->lb_clean = false;
             q.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
             q.state = reinterpret_cast<unsigned long long *>(ctx->lb + 16);
             HIP_TRY(ctx, launch_encode16_fast(q, aligned_out, ctx->stream));

@@ -89,9 +89,10 @@ struct EncParams {
     uint32_t lanes_per_row;
     uint32_t magic_w, magic_cpf, magic_lpr;   // div_magic_of(w), (chunks_per_frame), (lanes_per_row): divisions by launch constants
     uint32_t last_frame;           // n_frames - 1: no pixel load reaches past the end of that frame
-    uint32_t flags;                // bit 0: force ticket mode (A/B measurements)
+    uint32_t flags;                // bit 0: force ticket mode (A/B measurements); bit 6 (tests): small launches, odd chunks publish nothing
     uint32_t grid_blocks;          // resident workgroups of the persistent encoder
     unsigned long long *diag;      // [16] cycle counters, written only by -DDBDE_DIAG builds (profiles/variants.sh)
+    uint32_t small_epoch;          // launch_encode_small: tag of THIS launch's records (1 .. 2^30 - 1; records of other launches do not match)
 };
 
 struct DecParams {
@@ -111,6 +112,7 @@ struct DecParams {
     uint32_t fuse_epoch;            // ... of THIS launch (never 0; records of other launches do not match)
     uint32_t fuse_flags;            // bit 0 (tests): odd chunks publish nothing -- the waiting waves' fallback does the work
     DecGeom geom;
+    unsigned long long *diag;       // [16] written only by -DDBDE_DIAG builds (wave 0's timeline of the fused launch)
 };
 
 struct IdxParams {

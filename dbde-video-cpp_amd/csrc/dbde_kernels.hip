@@ -31,6 +31,31 @@
 
 namespace dbde {
 
+// -DDBDE_DIAG builds, one launch at a time (profiles/abbench, ABBENCH_SFDIAG): wave 0's wall-clock time (10 ns) at up
+// to ten points of a workgroup's life, summed over the launch's workgroups, plus the earliest and latest start and the
+// latest end -- where one frame per call spends its microseconds.
+#ifdef DBDE_DIAG
+#define SF_DECL uint64_t sfd[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SF_MARK(i) do { if (threadIdx.x == 0) sfd[i] = wall_clock64(); } while (0)
+#define SF_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define SF_FLUSH(diag, last)                                                                          \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && (diag)) {                                                             \
+            atomicMax(&(diag)[0], ~(unsigned long long)sfd[0]);                                       \
+            for (int i_ = 1; i_ < 10; i_++) atomicAdd(&(diag)[i_], (unsigned long long)sfd[i_]);      \
+            atomicAdd(&(diag)[10], 1ull);                                                             \
+            atomicMax(&(diag)[11], (unsigned long long)sfd[last]);                                    \
+            atomicMax(&(diag)[12], (unsigned long long)sfd[0]);                                       \
+            atomicAdd(&(diag)[13], (unsigned long long)sfd[0]);                                       \
+        }                                                                                             \
+    } while (0)
+#else
+#define SF_DECL
+#define SF_MARK(i)
+#define SF_DRAIN()
+#define SF_FLUSH(diag, last)
+#endif
+
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // native vector for the nontemporal builtins
 
 typedef unsigned long long u64a;   // type of the look-back records
@@ -1009,30 +1034,48 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
 // One frame per call (BASELINE configs[1] taken literally) is a chain of latencies, not a bandwidth problem:
 // with the persistent encoder a single 4096x3072 frame took 14.5 us, most of it the hand-off
 // AGG -> scanner round -> INC -> poll.  When the launch has no more chunks than the device holds workgroups,
-// every workgroup takes ONE chunk and works out its own prefix: it publishes its word count (AGG) and sums the
-// AGG records of the chunks in front of it -- two memory hops instead of four, no scanner workgroup, no
-// per-launch memset (the last workgroup to leave clears the records and counters for the next launch).
-// Chunk ids are arrival tickets, so every chunk in front of a workgroup belongs to a workgroup that is already
-// running: no assumption about dispatch order or residency; the spin is bounded all the same.
+// every workgroup takes ONE chunk -- chunk id = workgroup id -- and works out its own prefix: it publishes its word count
+// and sums the counts of the chunks in front of it.  A record is {launch epoch 32 | words 32}: records of older
+// launches carry older epochs (and the persistent encoder's AGG / INC records have bits 63:62 set, which no epoch
+// has), so nothing is drawn, cleared or reset per launch -- round 2's arrival ticket in front of the pixel loads and
+// its "last workgroup out clears the records" counter were 1.35 + 1.0 us of a 10.5 us launch (in-kernel timeline,
+// -DDBDE_DIAG).  Forward progress does not rest on dispatch order or co-residency: a record that has not appeared
+// after 30 us is computed by the waiting wave itself from the pixels (chunk_words_by_wave) -- every spin ends.
 struct EncSharedSmall {
     uint64_t pay[kEncWaves][kWaveWords + 64];
     uint32_t tot[kEncWaves];
-    uint32_t acc, chunk, pre[3];
+    uint32_t pre[kEncWaves][2];   // per wave: payload words in front of the chunk, in its frame / in the launch (partial sums)
+    uint32_t acc;
 };
+
+// Payload words of chunk j, by one wave, from the pixels (the fallback of encode_small_kernel's record wait).
+__device__ __forceinline__ uint32_t chunk_words_by_wave(const EncParams &p, uint32_t j, int lane) {
+    uint32_t sum = 0;
+    for (int tw = lane; tw < kEncThreads; tw += 64) {
+        const ChunkRef k2 = chunk_ref(p, j, tw);
+        const uint8_t *img = p.images + (size_t)k2.f * p.frame_pixels;
+        uint32_t v[16], mn, mx;
+        if (k2.hasA) { load_tile_generic(img, p.W, p.H, p.w, k2.t0, v); tile_minmax(v, mn, mx); sum += depth_of_range(mx - mn); }
+        if (k2.hasB) { load_tile_generic(img, p.W, p.H, p.w, k2.t0 + 1u, v); tile_minmax(v, mn, mx); sum += depth_of_range(mx - mn); }
+    }
+    return wave_sum(sum);
+}
 
 template <int IN_MODE, bool ALIGNED_OUT>
 __global__ __launch_bounds__(kEncThreads, 4) void encode_small_kernel(EncParams p) {
     __shared__ __attribute__((aligned(16))) EncSharedSmall sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        sh.chunk = atomicAdd(&p.ctrl[2], 1u);
-        sh.acc = 0;
-    }
+    SF_DECL;
+    SF_MARK(0);
+    if (tid == 0) sh.acc = 0;
     __syncthreads();
-    const uint32_t c = __builtin_amdgcn_readfirstlane(sh.chunk);
+    const uint32_t c = blockIdx.x;
+    SF_MARK(1);
     const ChunkRef k = chunk_ref(p, c, tid);
     uint32_t ra[16], rb[16];
     load_chunk<IN_MODE>(p, k, ra, rb);
+    SF_DRAIN();
+    SF_MARK(2);
     load_fixup_generic<IN_MODE>(p, k, ra, rb);
     uint32_t mnA, mxA, mnB, mxB;
     tile_minmax(ra, mnA, mxA);
@@ -1041,12 +1084,15 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_small_kernel(EncParams 
     const uint32_t dB = k.hasB ? depth_of_range(mxB - mnB) : 0u;
     const uint32_t incl = wave_scan_incl(dA + dB);
     const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
+    const u64a tag = (u64a)p.small_epoch << 32;
     if (lane == 0) {
         sh.tot[wave] = wtot;
         const uint32_t old = atomicAdd(&sh.acc, (1u << 24) | wtot);
-        if ((old >> 24) == (uint32_t)(kEncWaves - 1))   // last wave in: publish at once
-            __hip_atomic_store(&p.state[c], kStAgg | (u64a)((old & 0xFFFFFFu) + wtot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // last wave in: publish at once (flags bit 6, tests: odd chunks keep silent, as if they were not running yet)
+        if ((old >> 24) == (uint32_t)(kEncWaves - 1) && !((p.flags & 64u) && (c & 1u)))
+            __hip_atomic_store(&p.state[c], tag | (u64a)((old & 0xFFFFFFu) + wtot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    SF_MARK(3);
     // pack while the record travels (wave-private LDS region, wave-local offsets)
     uint64_t *pay = sh.pay[wave];
     const bool all8 = __builtin_amdgcn_readfirstlane(__all((dA == 8u || !k.hasA) && (dB == 8u || !k.hasB)));
@@ -1060,54 +1106,66 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_small_kernel(EncParams 
             pack_tile(rb, mnB, dB, pay, offB, kWaveWords + (uint32_t)lane);
         }
     }
-    // the chunk's prefixes: sum of the word counts in front of it, in its frame and in the launch
-    if (wave == 0) {
+    SF_MARK(4);
+    // the chunk's prefixes: sum of the word counts in front of it, in its frame and in the launch.  The records are read
+    // in groups of 64, group g by wave g mod 8: a single 4096x3072 frame (192 chunks) is one memory round trip for every
+    // workgroup, where one wave walking the groups in turn paid up to three
+    {
         const uint32_t fstart = k.f * p.chunks_per_frame;
         const uint64_t t_start = wall_clock64();
-        uint32_t inf = 0, glob = 0, ok = 1u;
-        for (uint32_t base = 0; base < c; base += 64u) {
+        uint32_t inf = 0, glob = 0;
+        for (uint32_t base = 64u * (uint32_t)wave; base < c; base += 64u * (uint32_t)kEncWaves) {
             const uint32_t j = base + (uint32_t)lane;
             u64a w = 0;
+            bool got = j >= c;
             for (;;) {
-                w = j < c ? __hip_atomic_load(&p.state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStAgg;
-                if (__all((int)((uint32_t)(w >> 62) == 1u))) break;
-                if (wall_clock64() - t_start > 200000000ull) { ok = 0u; break; }   // 2 s: give up, loudly
-                __builtin_amdgcn_s_sleep(2);
+                if (!got) { w = __hip_atomic_load(&p.state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = (w >> 32) == (tag >> 32); }
+                if (__all((int)got)) break;
+                if (wall_clock64() - t_start > 3000ull) {   // 30 us: whoever has not published may not be running yet
+                    uint64_t miss = __ballot((int)!got);
+                    while (miss) {
+                        const uint32_t kk = (uint32_t)__builtin_ctzll(miss);
+                        miss &= miss - 1ull;
+                        const uint32_t words = chunk_words_by_wave(p, base + kk, lane);
+                        if ((uint32_t)lane == kk) { w = words; got = true; }
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (!ok) break;
             const uint32_t v = j < c ? (uint32_t)w : 0u;
             glob += v;
             inf += j >= fstart ? v : 0u;
         }
         inf = wave_sum(inf);
         glob = wave_sum(glob);
-        if (lane == 0) {
-            sh.pre[0] = inf; sh.pre[1] = glob; sh.pre[2] = ok;
-            if (!ok) atomicOr(p.sticky, 1u);
-        }
+        if (lane == 0) { sh.pre[wave][0] = inf; sh.pre[wave][1] = glob; }
     }
+    SF_MARK(5);
     __syncthreads();
-    const uint32_t inf = sh.pre[0], glob = sh.pre[1];
+    SF_MARK(6);
+    uint32_t inf = 0, glob = 0;
     uint32_t wbase = 0, total = 0;
 #pragma unroll
     for (int q = 0; q < kEncWaves; q++) {
         const uint32_t tk = sh.tot[q];
         wbase += q < wave ? tk : 0u;
         total += tk;
+        inf += sh.pre[q][0];
+        glob += sh.pre[q][1];
     }
-    if (k.valid && sh.pre[2]) {
+    if (k.valid) {
         store_wave_part<ALIGNED_OUT>(p, k, dA | (dB << 8) | (mnA << 16) | (mnB << 24), wbase, wtot, inf, glob, pay, lane, all8 || DBDE_ENC_SWZ_ALL);
         if (tid == 64 * (kEncWaves - 1) && (k.cf == 0u || k.cf == p.chunks_per_frame - 1u))
             write_frame_fields<ALIGNED_OUT>(p, k.f, k.cf, inf + total, glob - inf);
     }
-    // leave the workspace as it was found: the last workgroup out clears the records and the counters
-    if (tid == 0) sh.chunk = atomicAdd(&p.ctrl[0], 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (sh.chunk) {
-        for (uint32_t j = (uint32_t)tid; j < p.n_chunks; j += (uint32_t)kEncThreads)
-            __hip_atomic_store(&p.state[j], (u64a)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < 4) __hip_atomic_store(&p.ctrl[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    SF_MARK(7);
+#ifdef DBDE_DIAG
+    SF_DRAIN();
+    SF_MARK(8);
+    SF_MARK(9);
+    SF_FLUSH(p.diag, 9);
+#endif
 }
 
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
@@ -1683,6 +1741,8 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     __shared__ uint32_t s_idx[G::kWaves][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SF_DECL;
+    SF_MARK(0);
     const uint32_t c = SELF_INDEX ? blockIdx.x : xcd_local_chunk(blockIdx.x, p.n_chunks);
     const uint32_t f = c / p.chunks_per_frame;
     const uint32_t cf = c - f * p.chunks_per_frame;
@@ -1790,6 +1850,11 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
             if (record) { res->u64s = 0xFFFFFFFFu; res->pad_ = 0; res->index = index; res->elapsed_ns = elapsed; res->consumed = 20ull; }
             return;
         }
+        // (the three I32 fields the verdict needs are requested here, with the depth bytes: asked for behind the record
+        // exchange they were one more memory round trip, 0.9 us of a 10 us launch)
+        const int32_t nb = (int32_t)load_u32_bytes(fb + 20);
+        const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
+        const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
         // 1. this chunk's depth sum and "a depth above 8" verdict
         const uint8_t *darr = fb + 24;
         const uint32_t te = t_begin + 2u * (uint32_t)tid;
@@ -1800,6 +1865,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         const bool wbad = __any((int)dbad);
         if (lane == 0) { s_idx[wave][0] = dsum; s_idx[wave][1] = wbad ? 1u : 0u; }
         __syncthreads();
+        SF_MARK(1);
         unsigned long long *rec = p.fuse_rec + (size_t)f * cpf;
         const unsigned long long tag = (unsigned long long)p.fuse_epoch << 32;
         if (tid == 0 && !((p.fuse_flags & 1u) && (cf & 1u))) {   // (fuse_flags bit 0, tests: odd chunks keep silent, as if not running)
@@ -1808,16 +1874,16 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
             for (int k = 0; k < G::kWaves; k++) { mine += s_idx[k][0]; mbad |= s_idx[k][1]; }
             __hip_atomic_store(&rec[cf], tag | ((unsigned long long)mbad << 31) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // 2. wave 0: the records of the frame's chunks
-        if (wave == 0) {
+        // 2. the records of the frame's chunks, in groups of 64 dealt to the workgroup's waves (group g to wave g mod 4), two
+        //    groups per trip with both loads in flight: a 384-chunk frame is ONE memory round trip per wave where a single
+        //    wave walking the six groups one after the other paid six
+        {
             const uint64_t t_start = wall_clock64();
             uint32_t before = 0, total = 0, flag = 0;
-            for (uint32_t base = 0; base < cpf; base += 64u) {
+            auto take = [&](const uint32_t base, unsigned long long w) __attribute__((always_inline)) {
                 const uint32_t k = base + (uint32_t)lane;
-                unsigned long long w = 0;
-                bool got = k >= cpf;
+                bool got = k >= cpf || (w >> 32) == (tag >> 32);
                 for (;;) {
-                    if (!got) { w = __hip_atomic_load(&rec[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = (w >> 32) == (tag >> 32); }
                     if (__all((int)got)) break;
                     if (wall_clock64() - t_start > 3000ull) {   // 30 us: whoever has not published may not be running yet
                         uint64_t miss = __ballot((int)!got);
@@ -1845,24 +1911,33 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
+                    if (!got) { w = __hip_atomic_load(&rec[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = (w >> 32) == (tag >> 32); }
                 }
                 const uint32_t v = k < cpf ? (uint32_t)w & 0x7FFFFFFFu : 0u;
                 total += v;
                 before += k < cf ? v : 0u;
                 flag |= k < cpf ? (uint32_t)(w >> 31) & 1u : 0u;
+            };
+            constexpr uint32_t kStride = 64u * (uint32_t)G::kWaves;
+            for (uint32_t base = 64u * (uint32_t)wave; base < cpf; base += 2u * kStride) {
+                const uint32_t kA = base + (uint32_t)lane, kB = kA + kStride;
+                const unsigned long long wA = kA < cpf ? __hip_atomic_load(&rec[kA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const unsigned long long wB = kB < cpf ? __hip_atomic_load(&rec[kB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                take(base, wA);
+                if (base + kStride < cpf) take(base + kStride, wB);
             }
             before = wave_sum(before); total = wave_sum(total);
             const bool anyflag = __any((int)flag);
-            if (lane == 0) { s_idx[0][2] = before; s_idx[0][3] = total; s_idx[1][2] = anyflag ? 1u : 0u; }
+            if (lane == 0) { s_idx[wave][2] = before; s_idx[wave][3] = total | (anyflag ? 0x80000000u : 0u); }   // (a frame holds < 2^31 words)
         }
+        SF_MARK(2);
         __syncthreads();
-        const uint32_t before = s_idx[0][2], total = s_idx[0][3], flag = s_idx[1][2];
+        uint32_t before = 0, total = 0, flag = 0;
+#pragma unroll
+        for (int k = 0; k < G::kWaves; k++) { before += s_idx[k][2]; total += s_idx[k][3] & 0x7FFFFFFFu; flag |= s_idx[k][3] >> 31; }
         uint32_t mine = 0;
 #pragma unroll
         for (int k = 0; k < G::kWaves; k++) mine += s_idx[k][0];
-        const int32_t nb = (int32_t)load_u32_bytes(fb + 20);
-        const int32_t nm = (int32_t)load_u32_bytes(fb + 24 + T);
-        const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
         const bool okf = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && !flag &&
                          in_extent(foff, need + 8ull * total, p.stream_bytes);
         if (record) {
@@ -1874,6 +1949,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         w_begin = before;
         w_end = before + mine;
         __syncthreads();   // s_idx and s_wave_tot are about to be reused
+        SF_MARK(3);
     } else {
         // everything the address arithmetic needs, requested together
         const uint32_t ok = p.frame_ok[f];
@@ -1930,6 +2006,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         const uint8_t *b = asrc + 16ull * n16_dma + (uint32_t)tid;
         reinterpret_cast<uint8_t *>(s_in)[16u * (swz ? swz16(n16_dma) : n16_dma) + (uint32_t)tid] = b < s_end ? *b : (uint8_t)0;
     }
+    SF_MARK(4);
     uint32_t dA = 0, dB = 0, mA = 0, mB = 0;
     // the lane's two tiles are one u16 load per array where that address is even
     if (hasB && ((reinterpret_cast<uintptr_t>(depth_arr + t0) | reinterpret_cast<uintptr_t>(min_arr + t0)) & 1u) == 0u) {
@@ -1946,8 +2023,10 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     // own DMA land (vmcnt) and its LDS writes retire (lgkmcnt) BEFORE it arrives at the barrier.  Stated
     // explicitly instead of relying on where the compiler happens to put its waits.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    SF_MARK(5);
     uint32_t chunk_total;   // equals chunk_words for a validated frame
     const uint32_t incl = block_scan_incl<G::kWaves>(dA + dB, s_wave_tot, lane, wave, chunk_total);   // barrier inside
+    SF_MARK(6);
     const uint32_t offA = incl - (dA + dB), offB = offA + dA;
 
     uint32_t va[16], vb[16];
@@ -1973,6 +2052,7 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         }
     }
 
+    SF_MARK(7);
     uint8_t *img = p.images + (size_t)f * p.frame_pixels;
     if (IMG == kImgDirect) {
         if (hasA) {   // W % 16 == 0: w is even and t_begin a multiple of w (or of 512), so both tiles share a tile row
@@ -1984,11 +2064,16 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
                 if (yy < p.H) {
                     u32x4_t o;
                     o[0] = va[2 * r]; o[1] = va[2 * r + 1]; o[2] = vb[2 * r]; o[3] = vb[2 * r + 1];
+                    // (plain stores for the single-frame launches, whose image nobody reads back, were measured: +1.4 us per round trip)
                     if (DBDE_NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W));
                     else *reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W) = o;
                 }
             }
         }
+        SF_MARK(8);
+        SF_DRAIN();
+        SF_MARK(9);
+        if (INDEX == kIdxFused) SF_FLUSH(p.diag, 9);
         return;
     }
 

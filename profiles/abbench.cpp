@@ -93,6 +93,38 @@ int main(int argc, char **argv) {
     double packed = 0;
     for (int i = 0; i < B; i++) packed += (double)hs[i];
     if (!getenv("ABBENCH_NOTIMING")) dbde_hip_timing_enable(c, 1);   // (the event pairs cost a few us per call: off for latency runs)
+    if (getenv("ABBENCH_SFDIAG")) {   // -DDBDE_DIAG builds, small launches (one frame per call): wave 0's timeline of ONE
+        // encode launch and ONE decode launch, averaged over the launch's workgroups, relative to the earliest start
+        using fn_diag = int (*)(ctx *, uint64_t *);
+        fn_diag dr = (fn_diag)dlsym(h, "dbde_hip_diag_read");
+        if (!dr) { fprintf(stderr, "no dbde_hip_diag_read\n"); return 1; }
+        dbde_hip_timing_enable(c, 0);
+        for (int i = 0; i < 20; i++) if (step()) return 1;
+        if (dbde_hip_sync(c)) return 1;
+        uint64_t d[16];
+        dr(c, d);
+        auto show = [&](const char *what, const char *const *names) {
+            if (!d[10]) { fprintf(stderr, "sfdiag %s: no record (not a -DDBDE_DIAG build, or not the small / fused kernels)\n", what); return; }
+            const double n = (double)d[10], t0 = (double)(~d[0]);
+            fprintf(stderr, "sfdiag %s: %llu workgroups, start spread %.2f us (mean start +%.2f), last end +%.2f us; wave 0 reaches (mean, us after the first start):",
+                    what, (unsigned long long)d[10], ((double)d[12] - t0) / 100.0, ((double)d[13] / n - t0) / 100.0, ((double)d[11] - t0) / 100.0);
+            for (int i = 1; i < 10; i++) fprintf(stderr, " %s %.2f", names[i], ((double)d[i] / n - t0) / 100.0);
+            fprintf(stderr, "\n");
+        };
+        static const char *en[10] = {"", "ticket", "pixels", "stats+AGG", "packed", "prefix", "barrier", "stores issued", "stores retired", "cleanup"};
+        static const char *dn[10] = {"", "depths summed", "records read", "validated", "DMA issued", "DMA landed", "scan", "unpacked", "stores issued", "stores retired"};
+        for (int rep = 0; rep < 3; rep++) {
+            if (dbde_hip_encode_frames(c, img, W, H, B, 0, nullptr, nullptr, buf + 32, cap, slot, offs, sizes)) return 1;
+            if (dbde_hip_sync(c)) return 1;
+            dr(c, d);
+            show("encode", en);
+            if (dbde_hip_decode_frames(c, buf + 32, cap, offs, W, H, B, out, nullptr)) return 1;
+            if (dbde_hip_sync(c)) return 1;
+            dr(c, d);
+            show("decode", dn);
+        }
+        return 0;
+    }
     double ms[4] = {0, 0, 0, 0};
     uint64_t n[4] = {0, 0, 0, 0};
     dbde_hip_timing_read(c, ms, n, 1);

@@ -50,7 +50,7 @@ def pixel_load_groups(lines):
     for i in idx:
         if cur:
             between = [ln.strip() for ln in lines[cur[-1] + 1:i]]
-            if i - cur[-1] > 40 or any(b.startswith((".LBB", "s_barrier", "s_cbranch", "s_branch")) or
+            if i - cur[-1] > 64 or any(b.startswith((".LBB", "s_barrier", "s_cbranch", "s_branch")) or
                                        re.match(r"s_waitcnt.*vmcnt", b) for b in between):
                 groups.append(cur)
                 cur = []

@@ -2064,7 +2064,8 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
                 if (yy < p.H) {
                     u32x4_t o;
                     o[0] = va[2 * r]; o[1] = va[2 * r + 1]; o[2] = vb[2 * r]; o[3] = vb[2 * r + 1];
-                    // (plain stores for the single-frame launches, whose image nobody reads back, were measured: +1.4 us per round trip)
+                    // (single-frame launches, whose image nobody reads back: plain stores measured +1.4 us per round trip, the sc0 / sc1 / nt
+                    // combinations within 0.5 us of each other -- the 4 us in which these stores retire are the memory side's)
                     if (DBDE_NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W));
                     else *reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W) = o;
                 }

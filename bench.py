@@ -491,7 +491,7 @@ def dry_run(args, world, rank, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)   # 60 x 8.4 ms: half a second of timed GPU work for the headline
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[config-1] as the headline")
     ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default: the config's)")

@@ -366,6 +366,14 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
 }
 
 // ---- batch decode ----------------------------------------------------------------------------
+#ifndef DBDE_STAGED_FILL
+// Percent of a workgroup's 512 tile slots that whole tile rows must fill for the staged decode path.  A workgroup's time
+// hardly depends on how many of its slots are used, so empty slots are lost throughput -- but tile-by-tile stores
+// (partial cache lines) cost more.  Measured on mixed content (round 3): 88 % fill (720, 1200, 600 wide) staged +4..9 %,
+// 84 % (3440) +3.5 %, 82 % (1680) equal, 79 % (1080 wide: portrait HD) equal and +26 % on incompressible frames,
+// 78 % (1600) -6 %, 70 % (1440) -4 %.
+#define DBDE_STAGED_FILL 79
+#endif
 
 int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes,
                            const uint64_t *d_frame_offsets, int W, int H, int n_frames, uint8_t *d_images,
@@ -377,13 +385,13 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     if (n_frames == 0) return DBDE_HIP_OK;
     // How the pixels reach the image (decode_kernel<IMG>): direct register -> image stores are only FAST when a
     // wave's 1 KB covers whole cache lines (W, the frame size and the base multiples of 128).  Other widths get
-    // chunks of whole tile rows where those fill a 512-tile workgroup to 90 % or more: the workgroup stages its pixels
-    // in LDS and writes whole cache lines of the chunk's byte range (odd widths: only workgroups whose tiles are all
-    // of depth 0 or 8, see the vote in decode_kernel).  Everything else stores tile by tile from plain chunks.
+    // chunks of whole tile rows where those fill enough of a 512-tile workgroup (DBDE_STAGED_FILL percent): the
+    // workgroup stages its pixels in LDS and writes whole cache lines of the chunk's byte range.  Everything else
+    // stores tile by tile from plain chunks.
     const uintptr_t ib = reinterpret_cast<uintptr_t>(d_images);
     int img_mode = 2;
     if (W % 128 == 0 && g.pixels % 128 == 0 && (ib & 127u) == 0) img_mode = 0;
-    else if (g.w <= kChunkTiles && W >= 16 && (kChunkTiles / g.w) * g.w * 10u >= kChunkTiles * 9u) {
+    else if (g.w <= kChunkTiles && W >= 16 && (kChunkTiles / g.w) * g.w * 100u >= kChunkTiles * (unsigned)DBDE_STAGED_FILL) {
         // image rows that are not 8-byte aligned are staged tile-aligned at pitch 8 w + 16: that image must fit the
         // workgroup's LDS (narrow frames have many rows per chunk and do not)
         const bool a8 = W % 8 == 0 && (ib & 7u) == 0;

@@ -2116,6 +2116,28 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
         if (hasB) store_tile_generic(img, p.W, p.H, p.w, t0 + 1u, vb);
         return;
     }
+    // 16-byte aligned image rows (W % 16 == 0, 16-byte aligned frames): a chunk that is NOT all of depth 8 stores straight
+    // from the registers, one aligned 16-byte store per lane and image row.  Its time goes into the unpack (LDS, VALU), and
+    // the staging's LDS traffic and barriers cost it more than the partial cache lines at the ends of a wave's rows do
+    // (mixed content at 88 % chunk fill: +4..9 %, 1680 wide +9 %); an all-depth-8 chunk is memory-bound and is staged
+    // (stored directly it lost 9..13 %).  The chunk's word count tells the two apart for the whole workgroup.
+    if (whole_rows && ((uint32_t)(reinterpret_cast<uintptr_t>(img) & 15u) | (Wu & 15u)) == 0u && chunk_words != 8u * n_tiles) {
+        if (hasA) {   // w is even: the lane's two tiles are neighbours in one tile row
+            const uint32_t iD = 2u * (uint32_t)tid, rowD = iD / wspan, colD = iD - rowD * wspan;
+            uint8_t *base = img + (size_t)(8u * colD);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t yy = y0 + 8u * rowD + (uint32_t)r;
+                if (yy < (uint32_t)p.H) {
+                    u32x4_t o;
+                    o[0] = va[2 * r]; o[1] = va[2 * r + 1]; o[2] = vb[2 * r]; o[3] = vb[2 * r + 1];
+                    if (DBDE_NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W));
+                    else *reinterpret_cast<u32x4_t *>(base + (size_t)yy * (size_t)p.W) = o;
+                }
+            }
+        }
+        return;
+    }
     __syncthreads();   // every wave has finished reading the payload image: the memory changes hands
     const uint32_t iA = 2u * (uint32_t)tid;
     const uint32_t rowA = iA / wspan, colA = iA - rowA * wspan;

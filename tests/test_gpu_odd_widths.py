@@ -41,7 +41,13 @@ def _encode_slots(codec, imgs, W, H, n, first_index=0, **kw):
 
 @pytest.mark.parametrize("W,H,n", [(513, 17, 3), (520, 9, 2), (1001, 33, 5), (1025, 64, 2), (2047, 8, 3), (4095, 24, 2),
                                    (1921, 1081, 2), (8200, 9, 2), (777, 777, 1), (515, 1, 4), (4096, 3072, 2), (2048, 2048, 3),
-                                   (1920, 1080, 2), (10, 10, 5), (15, 40, 3), (16, 16, 4), (33, 31, 7), (1, 1, 3), (200, 123, 6)])
+                                   (1920, 1080, 2), (10, 10, 5), (15, 40, 3), (16, 16, 4), (33, 31, 7), (1, 1, 3), (200, 123, 6),
+                                   # 16-byte aligned rows that are not whole cache lines: chunks of whole tile rows decode staged
+                                   # (all depth 8) or with direct 16-byte stores (anything else), per chunk; low chunk fill
+                                   # (1440, 1600 wide): direct 16-byte stores from plain chunks; few frames take the fused
+                                   # index + decode launch, many the index kernel; heights that end inside a tile
+                                   (720, 1283, 3), (720, 1283, 40), (1440, 900, 2), (1440, 900, 40), (1360, 765, 3), (1600, 20, 300),
+                                   (1080, 1925, 2), (1080, 1925, 30)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
 def test_slots_match_oracle(rows_codec, oracle, W, H, n, mode):
     import torch

@@ -2121,6 +2121,8 @@ __global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
     // the staging's LDS traffic and barriers cost it more than the partial cache lines at the ends of a wave's rows do
     // (mixed content at 88 % chunk fill: +4..9 %, 1680 wide +9 %); an all-depth-8 chunk is memory-bound and is staged
     // (stored directly it lost 9..13 %).  The chunk's word count tells the two apart for the whole workgroup.
+    // (Rows that are not 16-byte aligned gain nothing from the same idea: UNALIGNED 16-byte stores straight from the
+    // registers measured 4..13 % below the staged copy-out on 1921, 1928, 1080, 1001 wide mixed frames.)
     if (whole_rows && ((uint32_t)(reinterpret_cast<uintptr_t>(img) & 15u) | (Wu & 15u)) == 0u && chunk_words != 8u * n_tiles) {
         if (hasA) {   // w is even: the lane's two tiles are neighbours in one tile row
             const uint32_t iD = 2u * (uint32_t)tid, rowD = iD / wspan, colD = iD - rowD * wspan;

@@ -390,12 +390,27 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     // stores tile by tile from plain chunks.
     const uintptr_t ib = reinterpret_cast<uintptr_t>(d_images);
     int img_mode = 2;
+    uint32_t cap = kChunkTiles;   // tile slots of the workgroup that takes whole-tile-row chunks
     if (W % 128 == 0 && g.pixels % 128 == 0 && (ib & 127u) == 0) img_mode = 0;
-    else if (g.w <= kChunkTiles && W >= 16 && (kChunkTiles / g.w) * g.w * 100u >= kChunkTiles * (unsigned)DBDE_STAGED_FILL) {
-        // image rows that are not 8-byte aligned are staged tile-aligned at pitch 8 w + 16: that image must fit the
-        // workgroup's LDS (narrow frames have many rows per chunk and do not)
-        const bool a8 = W % 8 == 0 && (ib & 7u) == 0;
-        if (a8 || 8ull * (kChunkTiles / g.w) * (8ull * g.w + 16ull) <= 34048ull) img_mode = 1;
+    else if (g.w <= kChunkTiles && W >= 16) {
+        // whole tile rows in 512 slots (256 threads) or in 384 (192 threads), whichever they fill better
+        // (1366 wide: 2 x 171 tiles = 67 % of 512, 89 % of 384)
+        const uint32_t used512 = (kChunkTiles / g.w) * g.w;
+        const uint32_t used384 = g.w <= kChunkTilesSmall ? (kChunkTilesSmall / g.w) * g.w : 0u;
+        // (16-byte aligned rows are left out: there plain chunks with direct 16-byte stores, below, beat the better-filled
+        // small workgroup on mixed content -- 1440 / 2704 wide: 0.70 / 0.70 against 0.68 / 0.67)
+#ifndef DBDE_NO_SMALL_WG
+        if (W % 16 != 0 && (uint64_t)used384 * kChunkTiles > (uint64_t)used512 * kChunkTilesSmall) cap = kChunkTilesSmall;
+#endif
+        const uint32_t used = cap == kChunkTiles ? used512 : used384, rows = cap / g.w;
+        if (used * 100u >= cap * (unsigned)DBDE_STAGED_FILL) {
+            // image rows that are not 8-byte aligned are staged tile-aligned at pitch 8 w + 16: that image must fit the
+            // workgroup's LDS (narrow frames have many rows per chunk and do not); chunks of at most 384 tiles run on
+            // the smaller workgroup whatever `cap` says (launch_decode)
+            const bool a8 = W % 8 == 0 && (ib & 7u) == 0;
+            const uint64_t lds = used <= kChunkTilesSmall ? 25600ull : 34048ull;
+            if (a8 || 8ull * rows * (8ull * g.w + 16ull) <= lds) img_mode = 1;
+        }
     }
     // 16-byte aligned rows that neither cover whole cache lines per wave nor fill staged chunks: still ONE 16-byte store
     // per lane and image row (the direct form) instead of two 8-byte ones (1440 / 1600 wide: 0.62 -> 0.69 / 0.73)
@@ -406,7 +421,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
 #ifdef DBDE_FORCE_LINEAR
     img_mode = 1;
 #endif
-    const DecGeom dg = dec_geometry(g.w, g.h, img_mode == 1);
+    const DecGeom dg = dec_geometry(g.w, g.h, img_mode == 1, kChunkTiles, cap);
     const uint32_t dcpf = dg.cpf;   // whole tile rows (or pieces of a wide one) per chunk, one decode workgroup each
     if (dcpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
     const uint64_t n_chunks64 = (uint64_t)n_frames * dcpf;

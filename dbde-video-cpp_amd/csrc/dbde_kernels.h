@@ -9,6 +9,8 @@ namespace dbde {
 // (row-major over the frame's tiles), two tiles per lane.
 // Capacity of one decode workgroup: 256 threads, two tiles per lane.
 constexpr uint32_t kChunkTiles = 512;
+// ... and of the smaller decode workgroup (192 threads) that whole-tile-row chunks take when they fill it better
+constexpr uint32_t kChunkTilesSmall = 384;
 
 // Chunk geometry of the DECODER.  A chunk is the unit of one workgroup and always lines up with the image:
 //   * row-aligned form, w <= 512 tiles across: a chunk is a run of WHOLE tile rows (rows * w <= 512 tiles) --
@@ -25,13 +27,15 @@ struct DecGeom {
 };
 // row_aligned = false: plain runs of 512 consecutive tiles (a workgroup's time is nearly independent of how
 // many of its 512 tile slots are used, so full chunks win wherever alignment with the image buys nothing).
-__host__ __device__ inline DecGeom dec_geometry(uint32_t w, uint32_t h, bool row_aligned, uint32_t plain_ct = kChunkTiles) {
+// `cap`: tile slots of the workgroup that takes whole-tile-row chunks (kChunkTiles, or kChunkTilesSmall).
+__host__ __device__ inline DecGeom dec_geometry(uint32_t w, uint32_t h, bool row_aligned, uint32_t plain_ct = kChunkTiles,
+                                                uint32_t cap = kChunkTiles) {
     DecGeom g;
     g.w = w; g.h = h; g.T = w * h;
     if (!row_aligned) {
         g.ct = plain_ct; g.pieces = 1u; g.cpf = (g.T + plain_ct - 1u) / plain_ct;
-    } else if (w <= kChunkTiles) {
-        uint32_t rows = kChunkTiles / w;   // the staged image, 8 * rows * W <= 64 * rows * w bytes, fits 32 KiB
+    } else if (w <= cap) {
+        uint32_t rows = cap / w;   // the staged image, 8 * rows * W <= 64 * rows * w bytes, fits the workgroup's LDS
         if (rows < 1u) rows = 1u;
         g.ct = rows * w; g.pieces = 1u; g.cpf = (h + rows - 1u) / rows;
     } else {

@@ -1654,11 +1654,15 @@ __device__ __forceinline__ uint32_t xcd_local_chunk(uint32_t b, uint32_t n_chunk
 // LDS image of a chunk's payload: up to 15 bytes of alignment shift + 64 B per tile + one qword
 // of over-read, rounded up to whole 256-byte swizzle groups.  The same memory later holds the chunk's
 // decoded pixels on the staged (kImgLinear) path: 8 * rows * pitch <= 32 KiB (dec_geometry) + slack.
+// THREADS = 256 (512 tile slots) everywhere, plus 192 (384 slots) for whole-tile-row chunks that fill the smaller
+// workgroup better (dbde_capi.cpp: 1366 wide = 2 rows of 171 tiles: 67 % of 512, 89 % of 384); its image is three
+// quarters the size, so six of them are resident per CU.
+template <int THREADS = 256>
 struct DecLds {
-    static constexpr int kThreads = kChunkTiles / 2;
-    static constexpr int kWaves = kChunkTiles / 128;
+    static constexpr int kThreads = THREADS;
+    static constexpr int kWaves = THREADS / 64;
     // (and, on the staged-image path, 8 image-row pieces of 4096 B each shifted by up to 127 B: 8 * 4224 + 128)
-    static constexpr uint32_t kSlots = 2128u;   // 34,048 B: four workgroups per CU
+    static constexpr uint32_t kSlots = THREADS == 256 ? 2128u : 1600u;   // 34,048 B: four workgroups per CU; 25,600 B: six
     static constexpr int kPieces = (kSlots + kThreads - 1) / kThreads;   // 16-B pieces per thread
 };
 
@@ -1732,10 +1736,10 @@ constexpr int kImgDirect = 0, kImgLinear = 1, kImgTiles = 2;
 // the stream (the chunk's 512 depth bytes) -- every spin ends, whatever the dispatch order.
 constexpr int kIdxTable = 0, kIdxSelf = 1, kIdxFused = 2;
 
-template <int IMG, int INDEX>
-__global__ __launch_bounds__(kChunkTiles / 2) void decode_kernel(DecParams p) {
+template <int IMG, int INDEX, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void decode_kernel(DecParams p) {
     constexpr bool SELF_INDEX = INDEX == kIdxSelf;
-    typedef DecLds G;
+    typedef DecLds<THREADS> G;
     __shared__ __attribute__((aligned(16))) uint64_t s_in[G::kSlots * 2];
     __shared__ uint32_t s_wave_tot[G::kWaves];
     __shared__ uint32_t s_idx[G::kWaves][4];
@@ -2382,20 +2386,26 @@ hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t
     return hipGetLastError();
 }
 
-template <int IMG>
-static void launch_decode_img(const DecParams &p, int index_mode, dim3 grid, dim3 block, hipStream_t s) {
+template <int IMG, int THREADS = 256>
+static void launch_decode_img(const DecParams &p, int index_mode, dim3 grid, hipStream_t s) {
+    const dim3 block(THREADS);
     switch (index_mode) {
-        case kIdxTable: hipLaunchKernelGGL((decode_kernel<IMG, kIdxTable>), grid, block, 0, s, p); break;
-        case kIdxSelf: hipLaunchKernelGGL((decode_kernel<IMG, kIdxSelf>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((decode_kernel<IMG, kIdxFused>), grid, block, 0, s, p); break;
+        case kIdxTable: hipLaunchKernelGGL((decode_kernel<IMG, kIdxTable, THREADS>), grid, block, 0, s, p); break;
+        case kIdxSelf: hipLaunchKernelGGL((decode_kernel<IMG, kIdxSelf, THREADS>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((decode_kernel<IMG, kIdxFused, THREADS>), grid, block, 0, s, p); break;
     }
 }
+// The workgroup follows the chunk geometry: whole-tile-row chunks of at most 384 tiles (dec_geometry with that capacity)
+// run on 192 threads, everything else on 256.
 hipError_t launch_decode(const DecParams &p, int img_mode, int index_mode, hipStream_t s) {
-    dim3 grid(p.n_chunks), block(kChunkTiles / 2);
+    dim3 grid(p.n_chunks);
     switch (img_mode) {
-        case kImgDirect: launch_decode_img<kImgDirect>(p, index_mode, grid, block, s); break;
-        case kImgLinear: launch_decode_img<kImgLinear>(p, index_mode, grid, block, s); break;
-        default: launch_decode_img<kImgTiles>(p, index_mode, grid, block, s); break;
+        case kImgDirect: launch_decode_img<kImgDirect>(p, index_mode, grid, s); break;
+        case kImgLinear:
+            if (p.geom.pieces == 1u && p.geom.ct <= kChunkTilesSmall) launch_decode_img<kImgLinear, kChunkTilesSmall / 2>(p, index_mode, grid, s);
+            else launch_decode_img<kImgLinear>(p, index_mode, grid, s);
+            break;
+        default: launch_decode_img<kImgTiles>(p, index_mode, grid, s); break;
     }
     return hipGetLastError();
 }

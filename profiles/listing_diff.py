@@ -20,13 +20,14 @@ with tempfile.TemporaryDirectory() as tmp:
     for f in ("dbde_kernels.s", "dbde16_kernels.s"):
         old, new = bodies(f"{tmp}/dbde-video-cpp_amd/csrc/{f}"), bodies(f"{ROOT}/dbde-video-cpp_amd/csrc/{f}")
         for k, v in old.items():
-            cands = [k, k.replace("EEEvNS_9EncParamsE", "ELi1EEEvNS_9EncParamsE")]
+            cands = [k, k.replace("EEEvNS_9EncParamsE", "ELi1EEEvNS_9EncParamsE"), k.replace("EEEvNS_9DecParamsE", "ELi256EEEvNS_9DecParamsE")]
             k2 = next((c for c in cands if c in new), None)
             if k2 is None:
                 print("gone ", k); bad += 1
             elif new[k2] != v:
                 print("DIFF ", k2, len(v), "->", len(new[k2])); bad += 1
         for k in new:
-            if k not in old and k.replace("ELi1EEEvNS_9EncParamsE", "EEEvNS_9EncParamsE") not in old:
+            if k not in old and k.replace("ELi1EEEvNS_9EncParamsE", "EEEvNS_9EncParamsE") not in old and \
+                    k.replace("ELi256EEEvNS_9DecParamsE", "EEEvNS_9DecParamsE") not in old:
                 print("new  ", k, len(new[k]))
     print("identical" if not bad else f"{bad} kernels differ")

@@ -47,7 +47,11 @@ def _encode_slots(codec, imgs, W, H, n, first_index=0, **kw):
                                    # (1440, 1600 wide): direct 16-byte stores from plain chunks; few frames take the fused
                                    # index + decode launch, many the index kernel; heights that end inside a tile
                                    (720, 1283, 3), (720, 1283, 40), (1440, 900, 2), (1440, 900, 40), (1360, 765, 3), (1600, 20, 300),
-                                   (1080, 1925, 2), (1080, 1925, 30)])
+                                   (1080, 1925, 2), (1080, 1925, 30),
+                                   # whole tile rows that fill 384 tile slots better than 512: the 192-thread decode workgroup
+                                   # (odd rows, 8-byte rows, 16-byte rows; one and two tile rows per chunk; fused / index kernel)
+                                   (1366, 768, 2), (1366, 768, 40), (1365, 33, 50), (3000, 40, 3), (3000, 40, 60), (2704, 24, 30),
+                                   (1448, 900, 3), (2999, 17, 40)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
 def test_slots_match_oracle(rows_codec, oracle, W, H, n, mode):
     import torch

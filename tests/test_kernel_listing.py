@@ -152,7 +152,7 @@ def test_decoder_uses_sdwa_field_expansion(listing):
     """The decoder's field expansion is three SDWA shifts per four pixels: 96 in the general unpack of
     each instance (two tiles x eight rows x six); a rewrite that silently falls back to mask / bfe / shift-or chains
     shows here."""
-    body = "\n".join(function_body(listing, "_ZN4dbde13decode_kernelILi0ELi0EEEvNS_9DecParamsE"))
+    body = "\n".join(function_body(listing, "_ZN4dbde13decode_kernelILi0ELi0ELi256EEEvNS_9DecParamsE"))
     assert body.count("v_lshrrev_b32_sdwa") >= 96, body.count("v_lshrrev_b32_sdwa")
 
 

@@ -5,7 +5,9 @@
 //
 // Correctness-first companion of dbde_kernels.hip, same decomposition, ONE tile per lane (a tile row is 8 pixels =
 // 16 bytes, so every image access is still one 16-byte access per row and lane):
-//   encode: enc16_kernel  -- one pass: a workgroup per 256-tile chunk reduces, publishes its word count, packs, and
+//   encode: large launches of 16-byte aligned rows go through the 8-bit path's persistent encoder
+//           (dbde_kernels.hip: encode_kernel<IN, OUT, PIX = 2>); everything else:
+//           enc16_kernel  -- one pass: a workgroup per 256-tile chunk reduces, publishes its word count, packs, and
 //                            finds its prefix by summing the records in front of it (ticket order, two-level sums)
 //   decode: the 8-bit path's index kernels (IdxParams::min_bytes = 2) + dec16_kernel.
 // A tile row is the 8*d-bit integer at byte r*d of the tile payload, exactly as in the 8-bit format: rows are

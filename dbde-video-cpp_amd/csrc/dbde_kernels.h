@@ -145,8 +145,9 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 // DBDE16 (U16 pixels, W % 8 == 0, 16-byte aligned base) through the persistent encoder: 512 tiles per chunk, frame_pixels in bytes
 hipError_t launch_encode16_fast(const EncParams &p, bool aligned_out, hipStream_t s);
-// Launches with at most as many chunks as the device holds workgroups: one workgroup per chunk, no scanner,
-// self-cleaning workspace (records and counters are zero on entry and on exit).
+// Launches with at most as many chunks as the device holds workgroups: one workgroup per chunk (chunk id = workgroup id),
+// no scanner; records are tagged with EncParams::small_epoch and never cleared (the workspace only has to have been
+// zeroed once since it was allocated).
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
 // Frames of at most 64 tiles, one slot per frame: one tile per lane, 64 / T frames per wave, no workspace.

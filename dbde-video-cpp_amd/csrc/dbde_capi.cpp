@@ -283,6 +283,13 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
 }
 
 // ---- batch encode ----------------------------------------------------------------------------
+#ifndef DBDE_MID_ENCODE_TILES
+// Frames of 65 .. this many tiles, one slot each, encode with whole frames per workgroup (encode_mid_kernel, 0.46 of peak
+// on mixed content whatever T, 0.37 on incompressible frames); the chunk-per-frame kernels overtake it as T grows --
+// measured: T = 81 / 144 / 196 / 256 / 324 / 396 general path 0.12 / 0.19 / 0.25 / 0.32 / 0.36 / 0.40 mixed and
+// 0.15 / 0.27 / 0.35 / 0.44 / 0.50 / 0.53 incompressible.
+#define DBDE_MID_ENCODE_TILES 256
+#endif
 
 int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, int H, int n_frames,
                            uint64_t first_index, const uint64_t *d_indices, const uint64_t *d_elapsed_ns,
@@ -334,6 +341,15 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         return DBDE_HIP_OK;
     }
 
+#ifndef DBDE_NO_MID
+    if (g.T <= (unsigned)DBDE_MID_ENCODE_TILES && slot_stride != 0) {   // frames of 65 .. 256 tiles in slots: whole frames per workgroup (encode_mid_kernel)
+        span_begin(ctx, 0);
+        HIP_TRY(ctx, launch_encode_mid(p, (uint32_t)n_frames, ctx->stream));
+        span_end(ctx);
+        return DBDE_HIP_OK;
+    }
+#endif
+
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
     {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
         const size_t had = ctx->lb_bytes;
@@ -366,6 +382,12 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
 }
 
 // ---- batch decode ----------------------------------------------------------------------------
+#ifndef DBDE_MID_DECODE_TILES
+// Frames of up to this many tiles decode with whole frames per wave (T <= 64, decode_tiny_kernel) or per workgroup
+// (decode_mid_kernel): no index kernel, no chunk.  Measured wall time per step, mid against chunks + index kernel: T = 81 twice as
+// fast, 144 +24 %, 196 equal (mixed) / -14 % (incompressible), 256 -7 %.
+#define DBDE_MID_DECODE_TILES 160
+#endif
 #ifndef DBDE_STAGED_FILL
 // Percent of a workgroup's 512 tile slots that whole tile rows must fill for the staged decode path.  A workgroup's time
 // hardly depends on how many of its slots are used, so empty slots are lost throughput -- but tile-by-tile stores
@@ -432,14 +454,15 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     // couple of loads per thread: for a 4096x3072 frame (T = 196,608, 384 workgroups re-reading it) the same
     // idea took 38 us against 11 us for index + decode, measured.
     const bool self_index = g.T <= 8192u && n_chunks64 * (uint64_t)g.T <= (8ull << 20);
-    if (g.T <= 64u) {   // tiny frames (the tile-level entry points, thumbnails): several frames per wave, nothing else needed
+    if (g.T <= (unsigned)DBDE_MID_DECODE_TILES) {   // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup, nothing else needed
         DecParams tp;
         memset(&tp, 0, sizeof tp);
         tp.stream = d_stream; tp.frame_offsets = d_frame_offsets; tp.stream_bytes = stream_bytes;
         tp.images = d_images; tp.results = d_results; tp.frame_pixels = g.pixels;
         tp.W = W; tp.H = H; tp.w = g.w; tp.h = g.h; tp.T = g.T;
         span_begin(ctx, 2);
-        HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
+        if (g.T <= 64u) HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
+        else HIP_TRY(ctx, launch_decode_mid(tp, (uint32_t)n_frames, ctx->stream));
         span_end(ctx);
         return DBDE_HIP_OK;
     }

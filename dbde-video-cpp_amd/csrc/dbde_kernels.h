@@ -150,6 +150,11 @@ hipError_t launch_encode16_fast(const EncParams &p, bool aligned_out, hipStream_
 // zeroed once since it was allocated).
 hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 int encode_blocks_per_cu();
+// Frames of 65 .. 512 tiles, one slot per frame: one tile per lane, as many whole frames per 256 / 512 / 1024-thread
+// workgroup as fit (mid_threads_for), no workspace.
+hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t s);
+uint32_t mid_threads_for(uint32_t T);
+hipError_t launch_decode_mid(const struct DecParams &p, uint32_t n_frames, hipStream_t s);
 // Frames of at most 64 tiles, one slot per frame: one tile per lane, 64 / T frames per wave, no workspace.
 hipError_t launch_encode_tiny(const EncParams &p, uint32_t n_frames, hipStream_t s);
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);

@@ -1237,6 +1237,78 @@ hipError_t launch_encode_tiny(const EncParams &p, uint32_t n_frames, hipStream_t
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// ENCODE, frames between the tiny path and one chunk (64 < T <= 512 tiles: 72 .. 180 pixels a side), one slot per frame
+// ---------------------------------------------------------------------------------------
+// encode_tiny_kernel one level up: a lane still owns ONE tile, a WORKGROUP of 256 / 512 / 1024 threads holds as many
+// whole frames as fit (the host takes the size they fill best); the segmented scan goes through LDS.  The persistent and
+// small encoders give such a frame a whole 1024-tile chunk: 72x72 (T = 81) ran at 0.12 of peak, 96x96 at 0.18.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void encode_mid_kernel(EncParams p) {
+    constexpr int NW = THREADS / 64;
+    __shared__ uint32_t s_tot[NW];
+    __shared__ uint32_t s_incl[THREADS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t T = p.T, fpw = (uint32_t)THREADS / T;
+    const uint32_t fl = tid / T, t = tid - fl * T;
+    const uint32_t f = blockIdx.x * fpw + fl;
+    const bool active = fl < fpw && f < p.n_chunks;          // (n_chunks carries the frame count here)
+    uint32_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = 0;
+    if (active) load_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
+    uint32_t mn, mx;
+    tile_minmax(v, mn, mx);
+    const uint32_t d = active ? depth_of_range(mx - mn) : 0u;
+    uint32_t block_total;
+    const uint32_t incl = block_scan_incl<NW>(d, s_tot, (int)lane, (int)wave, block_total);
+    s_incl[tid] = incl;
+    __syncthreads();
+    if (!active) return;
+    const uint32_t first = fl * T;
+    const uint32_t base = first ? s_incl[first - 1u] : 0u;
+    const uint32_t prefix = incl - d - base, total = s_incl[first + T - 1u] - base;
+    uint8_t *fb = p.out + (uint64_t)f * p.slot_stride;
+    fb[24u + t] = (uint8_t)d;
+    fb[28u + T + t] = (uint8_t)mn;
+    uint8_t *dst = fb + 32ull + 2ull * T + 8ull * prefix;
+    const uint32_t mn4 = mn * 0x01010101u;   // every byte >= mn: no borrow crosses a byte
+    Funnel fn;
+    fn.reset();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint64_t word;
+        if (d != 0u && fn.push(pack_row(v[2 * r] - mn4, v[2 * r + 1] - mn4, d), 8u * d, word)) {
+            store_u64_any(dst, word);
+            dst += 8;
+        }
+    }
+    if (t == 0u) write_frame_fields<false>(p, f, 0u, total, 0u);   // header, the I32 fields, per-frame offset and size
+}
+
+// Threads of the workgroup that whole frames of T tiles (64 < T <= 512) fill best: 256, 512 or 1024.
+uint32_t mid_threads_for(uint32_t T) {
+    uint32_t best = 1024u, best_used = 0u;
+    for (uint32_t th = 256u; th <= 1024u; th *= 2u) {
+        if (th < T) continue;
+        const uint32_t used = (th / T) * T;
+        if ((uint64_t)used * best > (uint64_t)best_used * th) { best = th; best_used = used; }
+    }
+    return best;
+}
+
+hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t s) {
+    EncParams q = p;
+    q.n_chunks = n_frames;
+    q.chunks_per_frame = 1u;     // write_frame_fields: the one "chunk" is the frame's first and last
+    const uint32_t th = mid_threads_for(p.T), per_wg = th / p.T;
+    const dim3 grid((n_frames + per_wg - 1u) / per_wg);
+    if (th == 256u) hipLaunchKernelGGL(encode_mid_kernel<256>, grid, dim3(256), 0, s, q);
+    else if (th == 512u) hipLaunchKernelGGL(encode_mid_kernel<512>, grid, dim3(512), 0, s, q);
+    else hipLaunchKernelGGL(encode_mid_kernel<1024>, grid, dim3(1024), 0, s, q);
+    return hipGetLastError();
+}
+
 // Resident workgroups per CU of the encoder (occupancy query; LDS- and VGPR-bound).
 int encode_blocks_per_cu() {
     int n = 0;
@@ -2376,6 +2448,93 @@ __global__ __launch_bounds__(256) void decode_tiny_kernel(DecParams p) {
         v[2 * r + 1] = add_bytes(hi, mn4);
     }
     store_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
+}
+
+// ---------------------------------------------------------------------------------------
+// DECODE, frames just above the tiny path (64 < T <= kMidDecodeTiles): decode_tiny_kernel one level up
+// ---------------------------------------------------------------------------------------
+// A lane owns ONE tile, a WORKGROUP of 256 / 512 / 1024 threads as many whole frames as fit (mid_threads_for); the
+// frame's validation and the tile's word offset are a segmented scan over the depth bytes through LDS.  No index kernel,
+// no chunk: a 72x72 frame (81 tiles) in a 512-tile chunk behind a one-workgroup-per-frame index kernel ran at 0.22.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void decode_mid_kernel(DecParams p) {
+    constexpr int NW = THREADS / 64;
+    __shared__ uint32_t s_tot[NW];
+    __shared__ uint32_t s_incl[THREADS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t T = p.T, fpw = (uint32_t)THREADS / T;      // frames per workgroup
+    const uint32_t fl = tid / T, t = tid - fl * T;            // frame within the workgroup, tile within the frame
+    const uint32_t f = blockIdx.x * fpw + fl;
+    const bool active = fl < fpw && f < p.n_chunks;           // (n_chunks carries the frame count here)
+    const uint64_t need = 32ull + 2ull * T;
+    const uint64_t foff = active ? p.frame_offsets[f] : 0ull;
+    const bool in_range = active && in_extent(foff, need, p.stream_bytes);
+    const uint8_t *fb = p.stream + foff;
+    uint32_t d = 0, mn = 0;
+    if (in_range) { d = fb[24u + t]; mn = fb[28u + T + t]; }
+    // depth sum and "a depth above 8" count of every frame in one scan: low 20 bits words (<= 1024 * 255), above them flags
+    const uint32_t item = in_range ? (d | (d > 8u ? 1u << 20 : 0u)) : 0u;
+    uint32_t block_total;
+    const uint32_t incl = block_scan_incl<NW>(item, s_tot, (int)lane, (int)wave, block_total);
+    s_incl[tid] = incl;
+    __syncthreads();
+    if (!active) return;
+    const uint32_t first = fl * T;
+    const uint32_t base = first ? s_incl[first - 1u] : 0u;
+    const uint32_t upto = s_incl[first + T - 1u];
+    const uint32_t total = (upto - base) & 0xFFFFFu, n_bad = (upto - base) >> 20;
+    const uint32_t prefix = (incl - item - base) & 0xFFFFFu;  // payload words of the frame in front of this tile
+    bool ok = in_range;
+    if (ok) {
+        const int32_t nb = (int32_t)load_u32_bytes(fb + 20), nm = (int32_t)load_u32_bytes(fb + 24 + T);
+        const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
+        ok = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && n_bad == 0u &&
+             in_extent(foff, need + 8ull * total, p.stream_bytes);
+    }
+    if (t == 0u && p.results) {   // the frame's result record: dbde_unpack_frame's return value
+        uint32_t field = 0;
+        uint64_t index = 0, elapsed = 0;
+        if (in_extent(foff, 20, p.stream_bytes)) {
+            field = load_u32_bytes(fb);
+            index = load_u64_bytes(fb + 4);
+            elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
+        }
+        FrameResultDev *r = reinterpret_cast<FrameResultDev *>(p.results) + f;
+        r->u64s = (field == 2u && ok) ? 2u : 0xFFFFFFFFu;   // dbde_util.cpp:335,342
+        r->pad_ = 0;
+        r->index = index;
+        r->elapsed_ns = elapsed;
+        r->consumed = ok ? need + 8ull * total : 20ull;
+    }
+    if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
+    const uint8_t *pay = fb + need + 8ull * prefix, *s_end = p.stream + p.stream_bytes;
+    const uint32_t mn4 = mn * 0x01010101u;
+    uint32_t v[16];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint64_t row = 0;
+        if (d != 0u) {
+            const uint8_t *q = pay + (uint32_t)r * d;
+            if (q + 8 <= s_end) row = load_u64_any(q);
+            else for (uint32_t b = 0; b < d; b++) row |= (uint64_t)q[b] << (8u * b);   // the stream's last bytes: nothing past the extent
+        }
+        uint32_t lo, hi;
+        expand_row(row, d, lo, hi);
+        v[2 * r] = add_bytes(lo, mn4);
+        v[2 * r + 1] = add_bytes(hi, mn4);
+    }
+    store_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
+}
+
+hipError_t launch_decode_mid(const DecParams &p, uint32_t n_frames, hipStream_t s) {
+    DecParams q = p;
+    q.n_chunks = n_frames;
+    const uint32_t th = mid_threads_for(p.T), per_wg = th / p.T;
+    const dim3 grid((n_frames + per_wg - 1u) / per_wg);
+    if (th == 256u) hipLaunchKernelGGL(decode_mid_kernel<256>, grid, dim3(256), 0, s, q);
+    else if (th == 512u) hipLaunchKernelGGL(decode_mid_kernel<512>, grid, dim3(512), 0, s, q);
+    else hipLaunchKernelGGL(decode_mid_kernel<1024>, grid, dim3(1024), 0, s, q);
+    return hipGetLastError();
 }
 
 hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t s) {

@@ -728,6 +728,29 @@ def test_tiny_frames_many_per_wave(codec, oracle, W, H, n, mode):
         assert codec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
 
 
+@pytest.mark.parametrize("W,H,n", [(72, 72, 200), (96, 96, 150), (128, 128, 64), (160, 120, 90), (71, 73, 100), (176, 144, 41),
+                                   (520, 8, 30), (9, 600, 25), (180, 180, 7), (130, 121, 1), (65, 64, 513)])
+@pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
+def test_mid_frames_many_per_workgroup(codec, oracle, W, H, n, mode):
+    """Frames of 65 .. 512 tiles (72 .. 180 pixels a side): one tile per lane, as many whole frames per 256 / 512 / 1024
+    thread workgroup as fit (encode_mid_kernel for slots; decode_mid_kernel where it is the faster form); every frame
+    byte for byte against the oracle, both layouts, partial tiles, frame counts that leave the last workgroup part empty."""
+    import torch
+    imgs = codec.synth_frames(mode, SEED, 50, n, W, H)
+    imgs_h = imgs.cpu().numpy()
+    slot_bytes = ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
+    for slot in (slot_bytes, slot_bytes + 3, 0):
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=50, slot_stride=slot)
+        for f in range(n):
+            assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
+        total = int((offs[-1] + sizes[-1]).item())
+        canvas = torch.full_like(imgs, 0xEE)
+        back, res = codec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
+        codec.sync()
+        assert torch.equal(back, imgs), (W, H, mode, slot)
+        assert codec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
+
+
 @pytest.mark.parametrize("W,H,n,mode,concat", [(1921, 1081, 64, "noise8", True), (2048, 1024, 70, "mixed", False),
                                                (2048, 1024, 48, "mixed", True), (2048, 1024, 80, "smooth", False),
                                                (2048, 1024, 97, "mixed", True)])

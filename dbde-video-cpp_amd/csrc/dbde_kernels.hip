@@ -34,6 +34,9 @@ namespace dbde {
 // -DDBDE_DIAG builds, one launch at a time (profiles/abbench, ABBENCH_SFDIAG): wave 0's wall-clock time (10 ns) at up
 // to ten points of a workgroup's life, summed over the launch's workgroups, plus the earliest and latest start and the
 // latest end -- where one frame per call spends its microseconds.
+#ifndef DBDE_DIAG_LATE
+#define DBDE_DIAG_LATE 34   // -DDBDE_DIAG: first of the eight "late" step pairs whose duration is recorded (early: pairs 2-9)
+#endif
 #ifdef DBDE_DIAG
 #define SF_DECL uint64_t sfd[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define SF_MARK(i) do { if (threadIdx.x == 0) sfd[i] = wall_clock64(); } while (0)
@@ -971,16 +974,16 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     };
 #ifdef DBDE_DIAG
     uint32_t dg_pair = 0;
-    uint64_t dg_tp = __builtin_amdgcn_s_memtime(), dg_early = 0, dg_late = 0;
+    uint64_t dg_tp = wall_clock64(), dg_early = 0, dg_late = 0;   // (the constant 100 MHz clock: s_memtime follows the shader clock)
 #endif
     do {
         step(0u, r0a, r0b, r1a, r1b);
         step(1u, r1a, r1b, r0a, r0b);
 #ifdef DBDE_DIAG
-        {   // how long a pair of steps takes early in the launch (pairs 2..9) and later (pairs 34..41)
-            const uint64_t t = __builtin_amdgcn_s_memtime();
+        {   // how long a pair of steps takes early in the launch (pairs 2..9) and later (eight pairs from DBDE_DIAG_LATE on), in 10 ns
+            const uint64_t t = wall_clock64();
             if (dg_pair >= 2u && dg_pair < 10u) dg_early += t - dg_tp;
-            if (dg_pair >= 34u && dg_pair < 42u) dg_late += t - dg_tp;
+            if (dg_pair >= (unsigned)DBDE_DIAG_LATE && dg_pair < (unsigned)DBDE_DIAG_LATE + 8u) dg_late += t - dg_tp;
             dg_tp = t;
             dg_pair++;
         }

@@ -154,8 +154,8 @@ int main(int argc, char **argv) {
             if (d[11] && steps == 1) {   // one timed launch: when its workgroups started and the last one left (10 ns wall clock)
                 const double t0 = (double)(~d[11]);
                 fprintf(stderr, "diag[%s]: workgroups start within %.1f us, the last leaves %.1f us after the first start; a pair of steps takes "
-                        "%.0f cyc early in the launch (pairs 2-9), %.0f cyc later (pairs 34-41)\n", tag,
-                        ((double)d[12] - t0) / 100.0, ((double)d[14] - t0) / 100.0, d[15] / wg / 8.0, d[13] / wg / 8.0);
+                        "%.2f us early in the launch (pairs 2-9), %.2f us later (eight pairs from -DDBDE_DIAG_LATE on, default 34; wall clock)\n", tag,
+                        ((double)d[12] - t0) / 100.0, ((double)d[14] - t0) / 100.0, d[15] / wg / 8.0 / 100.0, d[13] / wg / 8.0 / 100.0);
             }
         }
     }

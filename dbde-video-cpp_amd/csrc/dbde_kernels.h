@@ -58,7 +58,10 @@ __host__ __device__ inline uint32_t dec_chunk_of(const DecGeom &g, uint32_t pos)
 }
 
 // The encoder walks larger chunks (fewer ticket draws): one 512-thread workgroup per 1024 tiles.
-constexpr uint32_t kEncChunkTiles = 1024;
+#ifndef DBDE_ENC_CHUNK_TILES
+#define DBDE_ENC_CHUNK_TILES 1024   // A/B switch (512: four-wave workgroups, half the step, twice the records)
+#endif
+constexpr uint32_t kEncChunkTiles = DBDE_ENC_CHUNK_TILES;
 
 // Decoupled look-back record, one per chunk, 64 bits, written and read with relaxed
 // agent-scope atomics (the record IS the flag, so no fence is needed):

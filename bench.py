@@ -529,6 +529,14 @@ def main():
     if world > 1 or os.environ.get("DBDE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:   # DBDE_BENCH_FORCE_DIST without a launcher: a one-rank rendezvous on the loopback interface
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1")):
+                os.environ.setdefault(k, v)
+            if "MASTER_PORT" not in os.environ:
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                sk.close()
         if args.dry_run:
             dist.init_process_group("gloo")
         elif rehearsal:

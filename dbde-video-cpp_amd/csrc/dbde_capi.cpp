@@ -453,6 +453,8 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
     // each reads the T depth bytes -- and the index kernel with its launch boundary is gone.  Only while T is a
     // couple of loads per thread: for a 4096x3072 frame (T = 196,608, 384 workgroups re-reading it) the same
     // idea took 38 us against 11 us for index + decode, measured.
+    // (Large batches of one-chunk frames gain nothing from it although each frame's depth bytes would be read only once:
+    // 262,144 frames of 128x128 took 1.75 ms self-indexed against 1.50 ms with the index kernel, measured.)
     const bool self_index = g.T <= 8192u && n_chunks64 * (uint64_t)g.T <= (8ull << 20);
     if (g.T <= (unsigned)DBDE_MID_DECODE_TILES) {   // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup, nothing else needed
         DecParams tp;

@@ -41,7 +41,7 @@ C_ABI_SYMBOLS = [
     "dbde_hip_unpack_8x8", "dbde_hip_unpack_8x8_partial", "dbde_hip_unpack_image", "dbde_hip_unpack_frame",
     "dbde_hip_pack_frame_header", "dbde_hip_pack_video_header",
     "dbde_hip_unpack_frame_header", "dbde_hip_unpack_video_header",
-    "dbde_hip_timing_enable", "dbde_hip_timing_read",
+    "dbde_hip_timing_enable", "dbde_hip_timing_read", "dbde_hip_encode_plan", "dbde_hip_decode_plan",
     "dbde_hip_stream_handle", "dbde_hip_device_index",
     "dbde16_hip_max_frame_bytes", "dbde16_hip_encode_frames", "dbde16_hip_decode_frames",
     "dbde_hip_writer_open", "dbde_hip_writer_put", "dbde_hip_writer_error", "dbde_hip_writer_close",
@@ -224,6 +224,38 @@ def gather_plan(nranks, rank, root, sizes, max_piece=0):
     ops = (GatherOp * max(n, 1))()
     lib().dbde_hip_gather_plan(nranks, rank, root, arr, max_piece, ops, n, None)
     return [(o.peer, o.kind, o.segment_offset, o.window_offset, o.bytes) for o in ops[:n]], total.value
+
+
+class LaunchPlan(C.Structure):
+    """dbde_hip_launch_plan (include/dbde_hip.h)."""
+    _fields_ = [("kernel", C.c_int32), ("input_mode", C.c_int32), ("image_mode", C.c_int32), ("index_mode", C.c_int32),
+                ("threads", C.c_int32), ("aligned_out", C.c_int32), ("chunks_per_frame", C.c_uint32),
+                ("chunk_tiles", C.c_uint32), ("n_chunks", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def encode_plan(W, H, n_frames, image_address=0, out_address=0, slot_stride=0, resident_workgroups=513):
+    """dbde_hip_encode_plan: which kernel form an encode call with these arguments runs (host arithmetic only)."""
+    pl = LaunchPlan()
+    L = lib()
+    L.dbde_hip_encode_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(LaunchPlan)]
+    rc = L.dbde_hip_encode_plan(W, H, n_frames, image_address, out_address, slot_stride, resident_workgroups, C.byref(pl))
+    if rc != OK:
+        raise ValueError(f"dbde_hip_encode_plan({W}, {H}, {n_frames}) -> {rc}")
+    return pl.as_dict()
+
+
+def decode_plan(W, H, n_frames, image_address=0, n_cu=256):
+    """dbde_hip_decode_plan: which kernel form a decode call with these arguments runs (host arithmetic only)."""
+    pl = LaunchPlan()
+    L = lib()
+    L.dbde_hip_decode_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(LaunchPlan)]
+    rc = L.dbde_hip_decode_plan(W, H, n_frames, image_address, n_cu, C.byref(pl))
+    if rc != OK:
+        raise ValueError(f"dbde_hip_decode_plan({W}, {H}, {n_frames}) -> {rc}")
+    return pl.as_dict()
 
 
 def gather_unique_id():

@@ -291,6 +291,40 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
 #define DBDE_MID_ENCODE_TILES 256
 #endif
 
+// Which kernel an encode call runs and on what chunk geometry: a pure function of the shape, the batch size, the
+// buffers' alignment, the layout and the number of workgroups the device holds (dbde_hip_encode_plan).
+struct EncPlan {
+    bool fast_in, aligned_out;
+    uint32_t enc_cpf, lanes_per_row;
+    uint64_t n_chunks64;
+    int kernel;            // 0 = persistent (encode_kernel), 1 = encode_small_kernel, 2 = encode_tiny_kernel, 3 = encode_mid_kernel
+};
+static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t images, uintptr_t out, uint64_t slot_stride,
+                           uint32_t enc_grid) {
+    EncPlan pl;
+    pl.fast_in = (W % 16 == 0) && ((images & 15u) == 0);
+#ifdef DBDE_FORCE_GENERIC   // A/B builds only: the any-geometry kernels on aligned images
+    pl.fast_in = false;
+#endif
+    // chunk geometry of the encoder (EncParams): plain runs of 1024 tiles, or -- any-geometry path, W >= 16 --
+    // 512 tile PAIRS that never leave a tile row
+    pl.enc_cpf = (g.T + kEncChunkTiles - 1) / kEncChunkTiles;
+    pl.lanes_per_row = 0;
+    if (!pl.fast_in && W >= 16) {
+        pl.lanes_per_row = (g.w + 1u) / 2u;
+        pl.enc_cpf = (uint32_t)(((uint64_t)g.h * pl.lanes_per_row + kEncChunkTiles / 2u - 1u) / (kEncChunkTiles / 2u));
+    }
+    pl.n_chunks64 = (uint64_t)n_frames * pl.enc_cpf;
+    pl.aligned_out = ((out & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
+    pl.kernel = 0;
+    if (g.T <= 64u && slot_stride != 0) pl.kernel = 2;          // tiny frames in slots: several frames per wave, nothing shared
+#ifndef DBDE_NO_MID
+    else if (g.T <= (unsigned)DBDE_MID_ENCODE_TILES && slot_stride != 0) pl.kernel = 3;   // 65 .. 256 tiles in slots: whole frames per workgroup
+#endif
+    else if (pl.n_chunks64 < enc_grid) pl.kernel = 1;           // fewer chunks than resident workgroups: one workgroup per chunk
+    return pl;
+}
+
 int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, int H, int n_frames,
                            uint64_t first_index, const uint64_t *d_indices, const uint64_t *d_elapsed_ns,
                            uint8_t *d_out, size_t out_capacity, uint64_t slot_stride,
@@ -301,20 +335,12 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
     if (n_frames == 0) return DBDE_HIP_OK;
     const uint64_t maxf = 32ull + 66ull * g.T;
-    bool fast_in = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_images) & 15u) == 0);
-#ifdef DBDE_FORCE_GENERIC   // A/B builds only: the any-geometry kernels on aligned images
-    fast_in = false;
-#endif
-    // chunk geometry of the encoder (EncParams): plain runs of 1024 tiles, or -- any-geometry path, W >= 16 --
-    // 512 tile PAIRS that never leave a tile row
-    uint32_t enc_cpf = (g.T + kEncChunkTiles - 1) / kEncChunkTiles, lanes_per_row = 0;
-    if (!fast_in && W >= 16) {
-        lanes_per_row = (g.w + 1u) / 2u;
-        enc_cpf = (uint32_t)(((uint64_t)g.h * lanes_per_row + kEncChunkTiles / 2u - 1u) / (kEncChunkTiles / 2u));
-    }
-    const uint64_t n_chunks64 = (uint64_t)n_frames * enc_cpf;
+    const EncPlan pl = plan_encode(g, W, n_frames, reinterpret_cast<uintptr_t>(d_images), reinterpret_cast<uintptr_t>(d_out), slot_stride,
+                                   ctx->enc_grid);
+    const bool fast_in = pl.fast_in, aligned_out = pl.aligned_out;
+    const uint32_t enc_cpf = pl.enc_cpf, lanes_per_row = pl.lanes_per_row;
+    const uint64_t n_chunks64 = pl.n_chunks64;
     if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: too many chunks in one call");
-    const bool aligned_out = ((reinterpret_cast<uintptr_t>(d_out) & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
     if (slot_stride) {
         if (slot_stride < maxf) return fail(ctx, DBDE_HIP_ERR_ARG, "encode_frames: slot_stride below the worst case");
         if ((uint64_t)(n_frames - 1) * slot_stride + maxf > out_capacity)
@@ -334,21 +360,19 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.indices = d_indices;
     p.elapsed_ns = d_elapsed_ns;
 
-    if (g.T <= 64u && slot_stride != 0) {   // tiny frames in slots: several frames per wave, nothing shared (encode_tiny_kernel)
+    if (pl.kernel == 2) {   // tiny frames in slots: several frames per wave, nothing shared (encode_tiny_kernel)
         span_begin(ctx, 0);
         HIP_TRY(ctx, launch_encode_tiny(p, (uint32_t)n_frames, ctx->stream));
         span_end(ctx);
         return DBDE_HIP_OK;
     }
 
-#ifndef DBDE_NO_MID
-    if (g.T <= (unsigned)DBDE_MID_ENCODE_TILES && slot_stride != 0) {   // frames of 65 .. 256 tiles in slots: whole frames per workgroup (encode_mid_kernel)
+    if (pl.kernel == 3) {   // frames of 65 .. 256 tiles in slots: whole frames per workgroup (encode_mid_kernel)
         span_begin(ctx, 0);
         HIP_TRY(ctx, launch_encode_mid(p, (uint32_t)n_frames, ctx->stream));
         span_end(ctx);
         return DBDE_HIP_OK;
     }
-#endif
 
     const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
     {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
@@ -358,7 +382,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         if (ctx->lb_bytes != had) ctx->lb_fresh = true;
     }
     // small launches (one frame per call above all): one workgroup per chunk, epoch-tagged records, no memset
-    const bool small = n_chunks < ctx->enc_grid;
+    const bool small = pl.kernel == 1;
     span_begin(ctx, 0);
     // A large launch clears what it is about to use (its records are zero / AGG / INC: bits 63:62, which no epoch has).
     // A small launch tags its records with its epoch and clears nothing -- except once per block, whose first bits are
@@ -397,20 +421,23 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
 #define DBDE_STAGED_FILL 79
 #endif
 
-int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes,
-                           const uint64_t *d_frame_offsets, int W, int H, int n_frames, uint8_t *d_images,
-                           dbde_hip_frame_result *d_results) {
-    if (!ctx) return DBDE_HIP_ERR_ARG;
-    Geometry g;
-    if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
-        return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
-    if (n_frames == 0) return DBDE_HIP_OK;
+// Which kernels a decode call runs: a pure function of the geometry, the batch size, the image base's alignment and the
+// device's CU count, so that the choice can be inspected and tested without a GPU (dbde_hip_decode_plan).
+struct DecPlan {
+    int img_mode;          // kImgDirect / kImgLinear / kImgTiles (dbde_kernels.hip)
+    uint32_t cap;          // tile slots of the workgroup that takes whole-tile-row chunks
+    DecGeom dg;
+    uint64_t n_chunks64;
+    bool self_index, fused;
+    int kernel;            // 0 = chunk kernels, 2 = decode_tiny_kernel, 3 = decode_mid_kernel
+};
+static DecPlan plan_decode(const Geometry &g, int W, int n_frames, uintptr_t ib, int n_cu, uint32_t exp_flags) {
+    DecPlan pl;
     // How the pixels reach the image (decode_kernel<IMG>): direct register -> image stores are only FAST when a
     // wave's 1 KB covers whole cache lines (W, the frame size and the base multiples of 128).  Other widths get
     // chunks of whole tile rows where those fill enough of a 512-tile workgroup (DBDE_STAGED_FILL percent): the
     // workgroup stages its pixels in LDS and writes whole cache lines of the chunk's byte range.  Everything else
     // stores tile by tile from plain chunks.
-    const uintptr_t ib = reinterpret_cast<uintptr_t>(d_images);
     int img_mode = 2;
     uint32_t cap = kChunkTiles;   // tile slots of the workgroup that takes whole-tile-row chunks
     if (W % 128 == 0 && g.pixels % 128 == 0 && (ib & 127u) == 0) img_mode = 0;
@@ -443,35 +470,56 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
 #ifdef DBDE_FORCE_LINEAR
     img_mode = 1;
 #endif
-    const DecGeom dg = dec_geometry(g.w, g.h, img_mode == 1, kChunkTiles, cap);
-    const uint32_t dcpf = dg.cpf;   // whole tile rows (or pieces of a wide one) per chunk, one decode workgroup each
-    if (dcpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
-    const uint64_t n_chunks64 = (uint64_t)n_frames * dcpf;
-    if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pl.img_mode = img_mode;
+    pl.cap = cap;
+    pl.dg = dec_geometry(g.w, g.h, img_mode == 1, kChunkTiles, cap);
+    pl.n_chunks64 = (uint64_t)n_frames * pl.dg.cpf;
     // Small frames (the tile-level entry points, thumbnails): the decode workgroups index the frame themselves --
     // each reads the T depth bytes -- and the index kernel with its launch boundary is gone.  Only while T is a
     // couple of loads per thread: for a 4096x3072 frame (T = 196,608, 384 workgroups re-reading it) the same
     // idea took 38 us against 11 us for index + decode, measured.
     // (Large batches of one-chunk frames gain nothing from it although each frame's depth bytes would be read only once:
     // 262,144 frames of 128x128 took 1.75 ms self-indexed against 1.50 ms with the index kernel, measured.)
-    const bool self_index = g.T <= 8192u && n_chunks64 * (uint64_t)g.T <= (8ull << 20);
-    if (g.T <= (unsigned)DBDE_MID_DECODE_TILES) {   // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup, nothing else needed
+    pl.self_index = g.T <= 8192u && pl.n_chunks64 * (uint64_t)g.T <= (8ull << 20);
+    // Few LARGE frames (one 4096x3072 frame per call: 384 chunks): the decode workgroups build the index among
+    // themselves (decode_kernel<IMG, kIdxFused>) -- no index kernel, no launch boundary.  Taken when the launch fits the
+    // device's workgroup slots (four per CU); correctness does not depend on that, only the latency does.
+    pl.fused = !pl.self_index && pl.n_chunks64 <= 4ull * (uint64_t)n_cu && !(exp_flags & 8u);
+    // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup
+    pl.kernel = g.T <= 64u ? 2 : (g.T <= (unsigned)DBDE_MID_DECODE_TILES ? 3 : 0);
+    return pl;
+}
+
+int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t stream_bytes,
+                           const uint64_t *d_frame_offsets, int W, int H, int n_frames, uint8_t *d_images,
+                           dbde_hip_frame_result *d_results) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    Geometry g;
+    if (!d_stream || !d_frame_offsets || !d_images || n_frames < 0 || !geometry(W, H, g))
+        return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: bad argument (W=%d H=%d n=%d)", W, H, n_frames);
+    if (n_frames == 0) return DBDE_HIP_OK;
+    const DecPlan pl = plan_decode(g, W, n_frames, reinterpret_cast<uintptr_t>(d_images), ctx->n_cu, ctx->exp_flags);
+    const int img_mode = pl.img_mode;
+    const DecGeom dg = pl.dg;
+    const uint32_t dcpf = dg.cpf;   // whole tile rows (or pieces of a wide one) per chunk, one decode workgroup each
+    if (dcpf > kMaxChunksPerFrame) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: frame too large");
+    const uint64_t n_chunks64 = pl.n_chunks64;
+    if (n_chunks64 >= (1ull << 31)) return fail(ctx, DBDE_HIP_ERR_ARG, "decode_frames: too many chunks in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool self_index = pl.self_index;
+    if (pl.kernel != 0) {   // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup, nothing else needed
         DecParams tp;
         memset(&tp, 0, sizeof tp);
         tp.stream = d_stream; tp.frame_offsets = d_frame_offsets; tp.stream_bytes = stream_bytes;
         tp.images = d_images; tp.results = d_results; tp.frame_pixels = g.pixels;
         tp.W = W; tp.H = H; tp.w = g.w; tp.h = g.h; tp.T = g.T;
         span_begin(ctx, 2);
-        if (g.T <= 64u) HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
+        if (pl.kernel == 2) HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
         else HIP_TRY(ctx, launch_decode_mid(tp, (uint32_t)n_frames, ctx->stream));
         span_end(ctx);
         return DBDE_HIP_OK;
     }
-    // Few large frames (one 4096x3072 frame per call: 384 chunks): the decode workgroups build the index among
-    // themselves (decode_kernel<IMG, kIdxFused>) -- no index kernel, no launch boundary.  Taken when the launch fits the
-    // device's workgroup slots (four per CU); correctness does not depend on that, only the latency does.
-    const bool fused = !self_index && n_chunks64 <= 4ull * (uint64_t)ctx->n_cu && !(ctx->exp_flags & 8u);
+    const bool fused = pl.fused;   // few large frames: the index is built inside the decode launch (plan_decode)
     if (fused) {
         const size_t had = ctx->fuse_rec_n;
         int rc = grow(ctx, ctx->fuse_rec, ctx->fuse_rec_n, (size_t)n_chunks64, sizeof(unsigned long long), true);
@@ -659,6 +707,43 @@ int dbde_hip_synth_frames(dbde_hip_ctx *ctx, int mode, uint64_t seed, uint64_t f
     if (n_frames == 0) return DBDE_HIP_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_synth(mode, seed, first_frame, n_frames, W, H, d_images, ctx->stream));
+    return DBDE_HIP_OK;
+}
+
+// ---- launch plans (pure functions: no context, no device) ------------------------------------------------------
+
+int dbde_hip_encode_plan(int W, int H, int n_frames, uint64_t image_address, uint64_t out_address, uint64_t slot_stride,
+                         int resident_workgroups, dbde_hip_launch_plan *plan) {
+    Geometry g;
+    if (!plan || n_frames < 1 || resident_workgroups < 1 || !geometry(W, H, g)) return DBDE_HIP_ERR_ARG;
+    const EncPlan pl = plan_encode(g, W, n_frames, (uintptr_t)image_address, (uintptr_t)out_address, slot_stride, (uint32_t)resident_workgroups);
+    memset(plan, 0, sizeof *plan);
+    plan->kernel = pl.kernel;
+    plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? 1 : 2);
+    plan->aligned_out = pl.aligned_out ? 1 : 0;
+    plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u));
+    plan->chunks_per_frame = pl.kernel >= 2 ? 0u : pl.enc_cpf;
+    plan->chunk_tiles = pl.kernel >= 2 ? 0u : kEncChunkTiles;
+    plan->n_chunks = pl.kernel >= 2 ? 0ull : pl.n_chunks64;
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_decode_plan(int W, int H, int n_frames, uint64_t image_address, int n_cu, dbde_hip_launch_plan *plan) {
+    Geometry g;
+    if (!plan || n_frames < 1 || n_cu < 1 || !geometry(W, H, g)) return DBDE_HIP_ERR_ARG;
+    const DecPlan pl = plan_decode(g, W, n_frames, (uintptr_t)image_address, n_cu, 0u);
+    memset(plan, 0, sizeof *plan);
+    plan->kernel = pl.kernel;
+    if (pl.kernel == 0) {
+        plan->image_mode = pl.img_mode;
+        plan->index_mode = pl.self_index ? 1 : (pl.fused ? 2 : 0);
+        plan->threads = pl.img_mode == 1 && pl.dg.pieces == 1u && pl.dg.ct <= kChunkTilesSmall ? (int32_t)(kChunkTilesSmall / 2u) : (int32_t)(kChunkTiles / 2u);
+        plan->chunks_per_frame = pl.dg.cpf;
+        plan->chunk_tiles = pl.dg.ct;
+        plan->n_chunks = pl.n_chunks64;
+    } else {
+        plan->threads = pl.kernel == 2 ? 256 : (int32_t)mid_threads_for(g.T);
+    }
     return DBDE_HIP_OK;
 }
 

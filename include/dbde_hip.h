@@ -307,6 +307,30 @@ typedef struct {
 int dbde_hip_gather_plan(int nranks, int rank, int root, const uint64_t *sizes, uint64_t max_piece,
                          dbde_hip_gather_op *ops, int max_ops, uint64_t *total_out);
 
+/* ---- launch plans: which kernels a batch call runs (pure host arithmetic: no context, no device) ------------
+ * The batch calls choose among several kernel forms by shape, batch size and buffer alignment;
+ * these two functions ARE that choice (dbde_hip_encode_frames / _decode_frames call the same code), exposed so that
+ * an integrator can see -- and a CPU-only test can pin -- what a given geometry runs.  No reference counterpart. */
+typedef struct dbde_hip_launch_plan {
+    int32_t kernel;            /* 0 = chunk kernels (encode: persistent encoder), 1 = encode: one workgroup per chunk
+                                  (small launches), 2 = whole frames per wave (T <= 64 tiles), 3 = whole frames per workgroup */
+    int32_t input_mode;        /* encode: 0 = 16-byte aligned rows, 1 = any geometry (W >= 16), 2 = byte by byte (W < 16) */
+    int32_t image_mode;        /* decode, kernel 0: 0 = one aligned 16-byte store per lane and image row, 1 = chunks of whole
+                                  tile rows staged in LDS (16-byte rows: per chunk, only all-depth-8 chunks stage),
+                                  2 = tile by tile */
+    int32_t index_mode;        /* decode, kernel 0: 0 = index kernel + table, 1 = self-indexing workgroups, 2 = fused index + decode */
+    int32_t threads;           /* workgroup size */
+    int32_t aligned_out;       /* encode: 1 = 8-byte aligned frames and fields (wide stores) */
+    uint32_t chunks_per_frame; /* kernels 0 / 1 */
+    uint32_t chunk_tiles;      /* kernels 0 / 1: tile slots of a chunk (decode: whole tile rows, or 512) */
+    uint64_t n_chunks;         /* kernels 0 / 1: chunks (= workgroups of the decoder) in the launch */
+} dbde_hip_launch_plan;
+/* resident_workgroups: what the device holds of the persistent encoder (2 per CU + 1 on MI355X: 513). */
+int dbde_hip_encode_plan(int width, int height, int n_frames, uint64_t image_address, uint64_t out_address,
+                         uint64_t slot_stride, int resident_workgroups, dbde_hip_launch_plan *plan);
+int dbde_hip_decode_plan(int width, int height, int n_frames, uint64_t image_address, int n_cu,
+                         dbde_hip_launch_plan *plan);
+
 /* ---- kernel timing hook for bench.py ---------------------------------------------------- */
 /* When enabled, every encode / decode call brackets its kernels with HIP events on the
  * context's stream; dbde_hip_timing_read returns accumulated milliseconds and launch counts

@@ -1,0 +1,104 @@
+"""CPU: which kernel form a batch call runs (dbde_hip_encode_plan / dbde_hip_decode_plan: the very functions
+dbde_hip_encode_frames / dbde_hip_decode_frames call, pure host arithmetic).  Pins the choices DESIGN.md 4.1 / 4.2
+describe, the BASELINE configs first, so that a change of a threshold shows up here and not only in a benchmark."""
+import pytest
+
+import dbde_video_cpp_amd as dv
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    dv.build()
+
+
+PERSISTENT, SMALL, TINY, MID = 0, 1, 2, 3
+DIRECT, STAGED, TILES = 0, 1, 2
+TABLE, SELF, FUSED = 0, 1, 2
+
+
+def test_baseline_configs():
+    # configs[1]: 4096x3072, 1024 frames per step
+    e = dv.encode_plan(4096, 3072, 1024, slot_stride=12976384)
+    assert (e["kernel"], e["input_mode"], e["threads"], e["chunk_tiles"], e["chunks_per_frame"]) == (PERSISTENT, 0, 512, 1024, 192)
+    d = dv.decode_plan(4096, 3072, 1024)
+    assert (d["kernel"], d["image_mode"], d["index_mode"], d["threads"], d["chunk_tiles"], d["chunks_per_frame"]) == (0, DIRECT, TABLE, 256, 512, 384)
+    # ... taken literally: ONE frame per call -> one workgroup per chunk / fused index + decode
+    assert dv.encode_plan(4096, 3072, 1)["kernel"] == SMALL
+    d1 = dv.decode_plan(4096, 3072, 1)
+    assert (d1["kernel"], d1["index_mode"], d1["n_chunks"]) == (0, FUSED, 384)
+    # configs[2]: 2048x2048 x 1000, concatenated
+    assert dv.encode_plan(2048, 2048, 1000)["kernel"] == PERSISTENT
+    assert dv.decode_plan(2048, 2048, 1000)["image_mode"] == DIRECT
+    # configs[3]: 1921x1081 -- any-geometry encoder, staged decode on chunks of two whole tile rows (2 x 241 tiles)
+    e = dv.encode_plan(1921, 1081, 2048, slot_stride=2168320)
+    assert (e["kernel"], e["input_mode"], e["aligned_out"]) == (PERSISTENT, 1, 1)
+    d = dv.decode_plan(1921, 1081, 2048)
+    assert (d["image_mode"], d["threads"], d["chunk_tiles"], d["chunks_per_frame"]) == (STAGED, 256, 482, 68)
+
+
+@pytest.mark.parametrize("W,H,mode,threads,chunk_tiles", [
+    (1920, 1080, DIRECT, 256, 512),     # whole cache lines per wave
+    (1280, 720, DIRECT, 256, 512),
+    (1440, 900, DIRECT, 256, 512),      # 16-byte rows, 70 % chunk fill: direct 16-byte stores from plain chunks
+    (1600, 900, DIRECT, 256, 512),      # 78 %
+    (720, 1280, STAGED, 256, 450),      # 16-byte rows, 88 % fill: whole tile rows (5 x 90), per-chunk direct / staged
+    (1360, 768, STAGED, 256, 510),
+    (1080, 1920, STAGED, 256, 405),     # 8-byte rows, 79 % fill (portrait HD)
+    (1928, 1080, STAGED, 256, 482),
+    (1366, 768, STAGED, 192, 342),      # odd rows, 2 x 171 tiles: 67 % of 512 slots, 89 % of 384 -> the 192-thread workgroup
+    (3000, 2000, STAGED, 192, 375),
+    (2999, 2001, STAGED, 192, 375),
+    (2200, 1000, TILES, 256, 512),      # 8-byte rows, 275 tiles: 54 % / 72 % fill -> tile by tile
+    (1001, 999, STAGED, 256, 504),
+])
+def test_decode_forms(W, H, mode, threads, chunk_tiles):
+    d = dv.decode_plan(W, H, 4096)
+    assert (d["kernel"], d["image_mode"], d["threads"], d["chunk_tiles"]) == (0, mode, threads, chunk_tiles), d
+
+
+def test_unaligned_image_base_changes_the_form():
+    assert dv.decode_plan(4096, 3072, 64, image_address=0)["image_mode"] == DIRECT
+    # a base that is not a multiple of 128: a wave's 1 KB no longer covers whole cache lines -> chunks of whole tile rows
+    # (one row of 512 tiles fills the workgroup), staged or, per chunk, direct 16-byte stores
+    for addr in (64, 16, 8, 1):
+        d = dv.decode_plan(4096, 3072, 64, image_address=addr)
+        assert (d["image_mode"], d["chunk_tiles"], d["chunks_per_frame"]) == (STAGED, 512, 384), (addr, d)
+    assert dv.encode_plan(4096, 3072, 64, image_address=0)["input_mode"] == 0
+    assert dv.encode_plan(4096, 3072, 64, image_address=1)["input_mode"] == 1
+    assert dv.encode_plan(4096, 3072, 64, out_address=0)["aligned_out"] == 1
+    assert dv.encode_plan(4096, 3072, 64, out_address=4)["aligned_out"] == 0
+
+
+@pytest.mark.parametrize("W,H,T,enc,dec,threads", [
+    (8, 8, 1, TINY, TINY, 256), (64, 64, 64, TINY, TINY, 256),
+    (72, 72, 81, MID, MID, 256),        # 3 frames per 256-thread workgroup (95 %)
+    (96, 96, 144, MID, MID, 1024),      # 7 frames per 1024 threads (98 %)
+    (128, 128, 256, MID, 0, 256),       # encode: one frame per 256 threads; decode: chunks again from 161 tiles on
+    (160, 120, 300, PERSISTENT, 0, 512), (320, 240, 1200, PERSISTENT, 0, 512),
+])
+def test_small_frames(W, H, T, enc, dec, threads):
+    slot = ((32 + 66 * T + 255) // 256) * 256
+    e = dv.encode_plan(W, H, 100000, slot_stride=slot)
+    d = dv.decode_plan(W, H, 100000)
+    assert e["kernel"] == enc and d["kernel"] == dec, (e, d)
+    if enc in (TINY, MID):
+        assert e["threads"] == threads
+    # concatenated frames need each other's sizes: the chunk kernels
+    assert dv.encode_plan(W, H, 100000, slot_stride=0)["kernel"] in (PERSISTENT, SMALL)
+
+
+def test_index_forms_follow_the_batch():
+    assert dv.decode_plan(200, 123, 13)["index_mode"] == SELF                 # few small frames: workgroups index themselves
+    assert dv.decode_plan(1024, 768, 6)["index_mode"] == FUSED                # 144 chunks fit the device: fused
+    assert dv.decode_plan(1024, 768, 6, n_cu=8)["index_mode"] == TABLE        # ... not a device of 8 CUs
+    assert dv.decode_plan(1024, 768, 4096)["index_mode"] == TABLE
+    assert dv.encode_plan(1024, 768, 6)["kernel"] == SMALL and dv.encode_plan(1024, 768, 4096)["kernel"] == PERSISTENT
+    assert dv.encode_plan(1024, 768, 6, resident_workgroups=9)["kernel"] == PERSISTENT
+
+
+def test_bad_arguments():
+    for bad in ((0, 8, 1), (8, 0, 1), (8, 8, 0)):
+        with pytest.raises(ValueError):
+            dv.decode_plan(*bad)
+        with pytest.raises(ValueError):
+            dv.encode_plan(*bad)

@@ -652,6 +652,21 @@ def main():
                 c = CONFIGS[4]
                 line["configs"]["4_headline_bytes"] = strip(b.case(c["W"], c["H"], 6144, c["content"], c["layout"], max(3, sub_steps // 2), 1))
                 line["configs"]["4_headline_bytes"]["workload"] = c["name"] + ", 6144 frames per launch (12.8 GB of pixels, as configs[1])"
+            if world == 1 and args.config == 2:
+                # shapes whose kernel forms differ from the configs' (DESIGN.md 4.2): same method, fewer steps, each gated on
+                # the reference's SHA-256 like the configs (tests/golden: made with the real reference)
+                line["shapes"] = {}
+                for (sw, sh_, sn, note) in ((1080, 1920, 2048, "portrait HD: 8-byte rows, staged decode at 79 % chunk fill"),
+                                            (1366, 768, 4096, "odd rows: any-geometry encoder, 192-thread staged decode"),
+                                            (1440, 900, 2048, "16-byte rows, not whole cache lines: direct 16-byte stores"),
+                                            (720, 1280, 4096, "16-byte rows, whole-tile-row chunks: direct or staged per chunk"),
+                                            (72, 72, 262144, "81 tiles: whole frames per workgroup, both directions")):
+                    try:
+                        r_ = strip(b.case(sw, sh_, sn, "mixed", "slots", max(3, sub_steps // 3), 1))
+                        r_["workload"] = f"{sn} frames of {sw}x{sh_}, mixed, slots; {note}"
+                        line["shapes"][f"{sw}x{sh_}"] = r_
+                    except Exception as e:   # reported, never fatal to the line
+                        line["shapes"][f"{sw}x{sh_}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # ---- gather pipeline (N > 1): BASELINE configs[4] -- the 10,000-frame 4096x3072 stream in rank blocks, batch k's
         # compressed bytes travelling to rank 0 while batch k+1 is encoded.  The headline and the contents above are
         # complete at this point; this leg is the one part that cannot be rehearsed on a one-GPU box (rank-to-rank RCCL

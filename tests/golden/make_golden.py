@@ -52,7 +52,11 @@ SMALL_SIZES = [(1, 1), (5, 3), (8, 8), (9, 17), (16, 24), (31, 33), (64, 64), (1
 MODES = {"noise8": 0, "mixed": 1, "flat": 2, "smooth": 3}
 
 BIG = [  # BASELINE.json configs 2, 3, 4 at the bench seeds: hashes only
-    ("cfg2_4096x3072", 3072, 4096), ("cfg3_2048x2048", 2048, 2048), ("cfg4_1921x1081", 1081, 1921)]
+    ("cfg2_4096x3072", 3072, 4096), ("cfg3_2048x2048", 2048, 2048), ("cfg4_1921x1081", 1081, 1921),
+    # shapes whose kernel forms differ from the configs' (round 3): portrait HD, 1366x768, 16-byte rows that are not
+    # whole cache lines, frames of 81 / 144 tiles
+    ("shape_1080x1920", 1920, 1080), ("shape_1366x768", 768, 1366), ("shape_1440x900", 900, 1440),
+    ("shape_720x1280", 1280, 720), ("shape_72x72", 72, 72), ("shape_96x96", 96, 96)]
 
 
 def sha(a):

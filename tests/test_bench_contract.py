@@ -39,6 +39,8 @@ def test_committed_bench_lines_follow_the_contract():
     # every timed configuration that has a reference-made fixture was also checked against it (not identity alone)
     assert d["contents"]["mixed"]["packed_sha_ok"] is True
     assert all(d["configs"][k]["packed_sha_ok"] is True for k in ("3", "4"))
+    if "shapes" in d:   # round 3 on: shapes whose kernel forms differ from the configs', gated on the reference's SHA-256 as well
+        assert all(v.get("packed_sha_ok") is True for v in d["shapes"].values()), d["shapes"]
     if "dbde16" in d:   # the extension's record (round 3 on): reported beside the headline, round trip checked
         assert d["dbde16"]["identical"] is True and d["dbde16"]["parity"].startswith("unpinned")
     assert d["cpu_baseline"]["mixed"]["value"] > 0 and d["cpu_baseline"]["mixed"]["mismatched_pixels"] == 0

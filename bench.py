@@ -183,9 +183,14 @@ def golden_sha(W, H, content):
             if e["W"] == W and e["H"] == H and e["mode"] == content}
 
 
+EXIT_EXCHANGE_FAILED = 3   # a rank that gave up on a stuck or failed exchange leaves with this code, never with 0
+
+
 class Watchdog:
     """The exchange legs are the one part of a multi-rank run that can hang (a collective nobody answers).  If the
-    block does not finish in `seconds`, `on_timeout()` runs (rank 0 prints the line it has) and the process leaves."""
+    block does not finish in `seconds`, `on_timeout()` runs (rank 0 prints the line it has) and the process leaves
+    NON-ZERO: it has touched the GPU and failed, and the launcher (torchrun / spawn_ranks) must see that.  The process
+    ends there -- it is never restarted or replaced."""
 
     def __init__(self, seconds, on_timeout):
         self.t = threading.Timer(seconds, self._fire)
@@ -197,7 +202,8 @@ class Watchdog:
             self.on_timeout()
         finally:
             sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(EXIT_EXCHANGE_FAILED)
 
     def __enter__(self):
         self.t.start()
@@ -266,19 +272,28 @@ class Bench:
             assert torch.equal(out, imgs), f"round trip mismatch ({W}x{H} {content} {layout})"
             # ... and not on round-trip identity alone (an encoder / decoder pair wrong in the same way would pass it):
             # the packed bytes of frames 0 and 3 against the SHA-256 of the REFERENCE's output for the same frames
-            want = golden_sha(W, H, content) if rank == 0 else {}
+            # EVERY rank is held to it: rank r's frames are r*B .. r*B + B - 1, the fixture holds frames r*1024 and
+            # r*1024 + 3 of the headline shape for r = 0..7 (tests/golden/make_golden.py RANK_FRAMES)
+            want = {fr - rank * B: v for fr, v in golden_sha(W, H, content).items() if 0 <= fr - rank * B < B}
             if want:
                 o_h, s_h = offs.cpu().numpy(), sizes.cpu().numpy()
                 sha_ok = True
                 for f, (sha, nbytes) in want.items():
-                    if f < B:
-                        got = buf[lead + int(o_h[f]):lead + int(o_h[f]) + int(s_h[f])].cpu().numpy().tobytes()
-                        sha_ok = sha_ok and len(got) == nbytes and hashlib.sha256(got).hexdigest() == sha
-                assert sha_ok, f"packed frames differ from the reference's ({W}x{H} {content})"
+                    got = buf[lead + int(o_h[f]):lead + int(o_h[f]) + int(s_h[f])].cpu().numpy().tobytes()
+                    sha_ok = sha_ok and len(got) == nbytes and hashlib.sha256(got).hexdigest() == sha
+                assert sha_ok, f"rank {rank}: packed frames differ from the reference's ({W}x{H} {content})"
             if scan:
                 assert torch.equal(found, offs), "stream scanner offsets differ from the encoder's"
                 assert int(count.item()) == B, "stream scanner lost frames"
         packed = int(sizes.sum().item())
+        # per rank: 1 = checked against the reference's SHA-256 and equal, -1 = no fixture for this rank's frames
+        # (a mismatch has already raised above)
+        sha_ranks = [sha_ok]
+        if self.dist is not None:
+            flag = torch.tensor([1 if sha_ok else -1], dtype=torch.int32, device=self.dev)
+            allf = [torch.zeros_like(flag) for _ in range(self.world)]
+            self.dist.all_gather(allf, flag)
+            sha_ranks = [True if int(x.item()) == 1 else None for x in allf]
 
         codec.timing(True)
         codec.timing_read(reset=True)
@@ -310,7 +325,7 @@ class Bench:
              "decode": {"ms": round(dec_ms, 4), "GBps": round(gbps(dec_ms), 1), "frac": round(gbps(dec_ms) / HBM_PEAK_GBPS, 4),
                         "index_ms": round(idx_ms, 4)},
              "round_trip_frac": round(2 * alg / (dt_max / steps) / 1e9 / HBM_PEAK_GBPS, 4),
-             "identical": bool(check), "packed_sha_ok": sha_ok}
+             "identical": bool(check), "packed_sha_ok": sha_ok, "packed_sha_ok_ranks": sha_ranks}
         if scan:
             r["decode"]["scan_ms"] = round(scan_ms, 4)
             r["decode"]["note"] = ("frame starts found on the device (speculative segment-parallel walk, exact by "
@@ -411,7 +426,35 @@ class Bench:
                 uid.copy_(torch.from_numpy(dv.gather_unique_id()))
             if self.dist is not None:
                 self.dist.broadcast(uid, src=0)
-            native = dv.Gather(self.codec, uid.cpu().numpy(), self.world, self.rank, root=0)
+            err = None
+            try:
+                native = dv.Gather(self.codec, uid.cpu().numpy(), self.world, self.rank, root=0)
+            except Exception as e:
+                err = e
+            # the outcome is AGREED before anyone moves on: a rank that failed alone would otherwise take the fallback
+            # (or skip the leg) while its peers sit in the native collective -- mismatched collectives, then the watchdog
+            if self.agree_failed(err is not None):
+                if native is not None:
+                    native.close()
+                raise RuntimeError(f"native gather unavailable on at least one rank (this rank: {err!r})")
+        try:
+            return self._stream_columns(W, H, n_total, batch, content, gather_mode, native, source, side, lo, hi, cols), (lo, hi)
+        finally:   # also on the exception path: an open Gather's destructor would wait on its comm stream
+            if native is not None:
+                native.close()
+            src_codec.close()
+
+    def agree_failed(self, failed):
+        """True on every rank if `failed` is true on any (one small all-reduce over the process group that is up)."""
+        if self.dist is None:
+            return bool(failed)
+        t = self.torch.tensor([1 if failed else 0], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    def _stream_columns(self, W, H, n_total, batch, content, gather_mode, native, source, side, lo, hi, cols):
+        from dbde_video_cpp_amd.streaming import RoundTripStream
+        torch = self.torch
         for name, g in (("resident_ring", None), ("kernels_only", None), ("with_gather", gather_mode)):
             if name == "with_gather" and g is None:
                 continue
@@ -426,13 +469,17 @@ class Bench:
                                       native=native if g == "native" else None, world=self.world, rank=self.rank)
             self.fence()
             rounds = -(-(-(-n_total // self.world)) // batch)      # batches of the largest rank block
+            err = None
             try:
                 r = rts.run(lo, hi - lo, self.world, self.rank, rounds=rounds)
             except Exception as e:
                 if not g:
                     raise
-                cols[name] = {"error": f"{type(e).__name__}: {e}"[:400]}   # the exchange failed: the other columns stand
-                self.failed_exchange = True
+                err = e
+            # agreed across ranks as well: the leg is taken or dropped by all of them
+            if g and self.agree_failed(err is not None):
+                cols[name] = {"error": (f"{type(err).__name__}: {err}" if err is not None else "failed on another rank")[:400]}
+                self.failed_exchange = True   # the exchange failed: the other columns stand
                 break
             t = torch.tensor([r["seconds"]], dtype=torch.float64, device=self.dev)
             if self.dist is not None:
@@ -453,10 +500,7 @@ class Bench:
                                           "nccl": "torch.distributed (RCCL) all_gather + batch_isend_irecv",
                                           "host": "gloo rehearsal through pinned host memory"}[g]
             del rts
-        if native is not None:
-            native.close()
-        src_codec.close()
-        return cols, (lo, hi)
+        return cols
 
 
 def dry_run(args, world, rank, dist):

@@ -39,9 +39,12 @@ struct dbde_hip_ctx {
     std::string err;
     std::string arch;
 
-    // look-back workspace: [ctrl: 4 x u32][state: n_chunks x u64], zeroed before every encode
+    // look-back workspace: [two sets of control words: 2 x 8 x u32][state: n_chunks x u64].  Zeroed when it is allocated
+    // and after a failed launch; otherwise every launch leaves it as it found it (persistent encoder: each record is
+    // cleared by its reader, the scanner clears the control words of the launch after it; small launches tag theirs)
     uint8_t *lb = nullptr;
     size_t lb_bytes = 0;
+    uint32_t enc_parity = 0;         // which set of control words the next persistent launch uses
     // scan-ahead: a second stream so that the frame-to-frame walk of the NEXT batch runs beside the decode of this one
     hipStream_t scan_stream = nullptr;
     hipEvent_t scan_ev_main = nullptr, scan_ev_done = nullptr;
@@ -184,15 +187,21 @@ int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out) {
         int per_cu = encode_blocks_per_cu();
         if (const char *g = getenv("DBDE_HIP_ENC_BLOCKS_PER_CU")) per_cu = atoi(g) > 0 ? atoi(g) : per_cu;
         ctx->enc_grid = (uint32_t)(per_cu * prop.multiProcessorCount);
+        if (ctx->enc_grid > kEncMaxGrid) ctx->enc_grid = kEncMaxGrid;   // one mode flag per workgroup (attach_lookback)
         ctx->n_cu = prop.multiProcessorCount;
     }
     if (const char *e = getenv("DBDE_HIP_EXPERIMENT")) ctx->exp_flags = (uint32_t)strtoul(e, nullptr, 0);
     void *p = nullptr;
-    if (hipMalloc(&p, 64 + 128) != hipSuccess) { delete ctx; return DBDE_HIP_ERR_HIP; }
+#ifdef DBDE_DIAG
+    const size_t small_block = 64 + 128 + 8 * 16 * 1024;   // + per-workgroup timeline of the persistent encoder ([1024][16] u64)
+#else
+    const size_t small_block = 64 + 128;
+#endif
+    if (hipMalloc(&p, small_block) != hipSuccess) { delete ctx; return DBDE_HIP_ERR_HIP; }
     ctx->sticky = reinterpret_cast<uint32_t *>(p);
     ctx->scratch64 = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(p) + 16);
     ctx->diag = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(p) + 64);
-    if (hipMemsetAsync(p, 0, 64 + 128, ctx->stream) != hipSuccess) { (void)hipFree(p); delete ctx; return DBDE_HIP_ERR_HIP; }
+    if (hipMemsetAsync(p, 0, small_block, ctx->stream) != hipSuccess) { (void)hipFree(p); delete ctx; return DBDE_HIP_ERR_HIP; }
     *out = ctx;
     return DBDE_HIP_OK;
 }
@@ -224,6 +233,7 @@ int dbde_hip_sync(dbde_hip_ctx *ctx) {
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->sticky, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (flag) {
+        ctx->lb_fresh = true;   // the failed launch left its records behind: the next encode clears the workspace first
         HIP_TRY(ctx, hipMemsetAsync(ctx->sticky, 0, 4, ctx->stream));
         return fail(ctx, DBDE_HIP_ERR_DEVICE, "encode kernel: chunk look-back timed out");
     }
@@ -264,6 +274,9 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
     p.first_index = first_index;
     p.state = nullptr;
     p.ctrl = nullptr;
+    p.ctrl_next = nullptr;
+    p.mode_flags = nullptr;
+    p.launch_epoch = 0;
     p.sticky = ctx->sticky;
     p.slot_stride = slot_stride;
     p.frame_pixels = (uint64_t)pix * g.pixels;   // bytes of one frame's image
@@ -271,6 +284,7 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
     p.chunks_per_frame = chunks_per_frame;
     p.n_chunks = (uint32_t)n_frames * chunks_per_frame;
     p.lanes_per_row = lanes_per_row;
+    p.pairs_per_wave = 64u;
     p.magic_w = div_magic_of(g.w);
     p.magic_cpf = div_magic_of(chunks_per_frame);
     p.magic_lpr = div_magic_of(lanes_per_row);
@@ -280,6 +294,42 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
     p.diag = reinterpret_cast<unsigned long long *>(ctx->diag);
     p.small_epoch = 0;
     return p;
+}
+
+// The encoders' shared workspace: [control words, set 0: 8 x u32][set 1][records: n_chunks x u64].  NO memset in front
+// of a launch (round 3 cleared it before every persistent launch: a fill kernel and its boundary, 8-10 us of each):
+//   * a persistent launch finds zeros where it needs them and leaves zeros behind -- every AGG / INC record is cleared
+//     by the workgroup that reads it (wait_inc), the control words it uses were cleared by the launch before it (the
+//     scanner clears the OTHER set; launches alternate), and records of small launches (below) have bits 63:62 clear,
+//     which no AGG / INC record has;
+//   * a small launch tags its records with its epoch and clears nothing.
+// The block is zeroed when it is (re)allocated, when the small launches' epoch wraps, and after a launch that failed
+// (dbde_hip_sync saw the sticky word: until then the context's launches return at once, encode_kernel).
+static int attach_lookback(dbde_hip_ctx *ctx, EncParams &p, uint32_t n_chunks, bool small) {
+    // two sets of control words | the mode flags | records
+    constexpr size_t kFlagsAt = 2 * 4 * (size_t)kEncCtrlWords, kHeader = (kFlagsAt + 4 * (size_t)kEncMaxGrid + 4095) & ~(size_t)4095;
+    const size_t lb_need = (kHeader + 8 * (size_t)n_chunks + 15) & ~(size_t)15;
+    {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
+        const size_t had = ctx->lb_bytes;
+        int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, !(ctx->exp_flags & 128u));   // (experiment bit 7: plain cached memory)
+        if (rc) return rc;
+        if (ctx->lb_bytes != had) ctx->lb_fresh = true;
+    }
+    if (ctx->lb_fresh || ctx->enc_epoch >= (1u << 30) - 1u) {   // (small launches' record tags and persistent launches' mode flags share the epoch counter)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
+        ctx->lb_fresh = false;
+        ctx->enc_epoch = 0;
+        ctx->enc_parity = 0;
+    }
+    const uint32_t epoch = ++ctx->enc_epoch;
+    p.small_epoch = small ? epoch : 0u;
+    p.launch_epoch = epoch;
+    p.ctrl = reinterpret_cast<uint32_t *>(ctx->lb) + kEncCtrlWords * ctx->enc_parity;
+    p.ctrl_next = reinterpret_cast<uint32_t *>(ctx->lb) + kEncCtrlWords * (ctx->enc_parity ^ 1u);
+    p.mode_flags = reinterpret_cast<uint32_t *>(ctx->lb + kFlagsAt);
+    p.state = reinterpret_cast<unsigned long long *>(ctx->lb + kHeader);
+    if (!small) ctx->enc_parity ^= 1u;
+    return DBDE_HIP_OK;
 }
 
 // ---- batch encode ----------------------------------------------------------------------------
@@ -295,7 +345,7 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
 // buffers' alignment, the layout and the number of workgroups the device holds (dbde_hip_encode_plan).
 struct EncPlan {
     bool fast_in, aligned_out;
-    uint32_t enc_cpf, lanes_per_row;
+    uint32_t enc_cpf, lanes_per_row, pairs_per_wave;
     uint64_t n_chunks64;
     int kernel;            // 0 = persistent (encode_kernel), 1 = encode_small_kernel, 2 = encode_tiny_kernel, 3 = encode_mid_kernel
 };
@@ -310,9 +360,19 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
     // 512 tile PAIRS that never leave a tile row
     pl.enc_cpf = (g.T + kEncChunkTiles - 1) / kEncChunkTiles;
     pl.lanes_per_row = 0;
+    pl.pairs_per_wave = 64;
     if (!pl.fast_in && W >= 16) {
         pl.lanes_per_row = (g.w + 1u) / 2u;
-        pl.enc_cpf = (uint32_t)(((uint64_t)g.h * pl.lanes_per_row + kEncChunkTiles / 2u - 1u) / (kEncChunkTiles / 2u));
+        // Dword-aligned fetches (kInRaw4: a 16-byte load at an odd address runs at 0.87 of the rate of one at any even
+        // address): a wave owns 63 pairs, its 64th lane feeds the 63rd.  Taken when the last pair of a tile row holds at
+        // most 13 pixel columns -- the up to 3 bytes its moved fetch is short of are then padding (dbde_kernels.hip).
+        // Rows at even addresses (W and the base even) read at the full rate as they are and keep 64 pairs.
+#ifndef DBDE_NO_RAW4
+        const uint32_t last_cols = (uint32_t)W - 16u * (pl.lanes_per_row - 1u);
+        if (last_cols <= 13u && ((W | (int)(images & 1u)) & 1)) pl.pairs_per_wave = 63;
+#endif
+        const uint32_t ppc = pl.pairs_per_wave * (kEncChunkTiles / 128u);
+        pl.enc_cpf = (uint32_t)(((uint64_t)g.h * pl.lanes_per_row + ppc - 1u) / ppc);
     }
     pl.n_chunks64 = (uint64_t)n_frames * pl.enc_cpf;
     pl.aligned_out = ((out & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
@@ -359,6 +419,7 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
                              d_frame_offsets, d_frame_bytes);
     p.indices = d_indices;
     p.elapsed_ns = d_elapsed_ns;
+    p.pairs_per_wave = pl.pairs_per_wave;
 
     if (pl.kernel == 2) {   // tiny frames in slots: several frames per wave, nothing shared (encode_tiny_kernel)
         span_begin(ctx, 0);
@@ -374,31 +435,13 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         return DBDE_HIP_OK;
     }
 
-    const size_t lb_need = (16 + 8 * (size_t)n_chunks + 15) & ~(size_t)15;   // zeroed as a whole, multiple of 16
-    {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
-        const size_t had = ctx->lb_bytes;
-        int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);
-        if (rc) return rc;
-        if (ctx->lb_bytes != had) ctx->lb_fresh = true;
-    }
-    // small launches (one frame per call above all): one workgroup per chunk, epoch-tagged records, no memset
+    // small launches (one frame per call above all): one workgroup per chunk, epoch-tagged records
     const bool small = pl.kernel == 1;
     span_begin(ctx, 0);
-    // A large launch clears what it is about to use (its records are zero / AGG / INC: bits 63:62, which no epoch has).
-    // A small launch tags its records with its epoch and clears nothing -- except once per block, whose first bits are
-    // arbitrary, and when the epoch counter wraps.
-    if (!small) HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
-    else {
-        if (ctx->lb_fresh || ctx->enc_epoch >= (1u << 30) - 1u) {
-            HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, ctx->lb_bytes, ctx->stream));
-            ctx->lb_fresh = false;
-            ctx->enc_epoch = 0;
-        }
-        p.small_epoch = ++ctx->enc_epoch;
+    {
+        int rc = attach_lookback(ctx, p, n_chunks, small);
+        if (rc) return rc;
     }
-
-    p.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
-    p.state = reinterpret_cast<unsigned long long *>(ctx->lb + 16);
     if (small) HIP_TRY(ctx, launch_encode_small(p, fast_in, aligned_out, ctx->stream));
     else HIP_TRY(ctx, launch_encode(p, fast_in, aligned_out, ctx->stream));
     span_end(ctx);
@@ -719,11 +762,11 @@ int dbde_hip_encode_plan(int W, int H, int n_frames, uint64_t image_address, uin
     const EncPlan pl = plan_encode(g, W, n_frames, (uintptr_t)image_address, (uintptr_t)out_address, slot_stride, (uint32_t)resident_workgroups);
     memset(plan, 0, sizeof *plan);
     plan->kernel = pl.kernel;
-    plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? 1 : 2);
+    plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? (pl.pairs_per_wave == 63u ? 3 : 1) : 2);
     plan->aligned_out = pl.aligned_out ? 1 : 0;
     plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u));
     plan->chunks_per_frame = pl.kernel >= 2 ? 0u : pl.enc_cpf;
-    plan->chunk_tiles = pl.kernel >= 2 ? 0u : kEncChunkTiles;
+    plan->chunk_tiles = pl.kernel >= 2 ? 0u : (pl.lanes_per_row ? 2u * pl.pairs_per_wave * (kEncChunkTiles / 128u) : kEncChunkTiles);
     plan->n_chunks = pl.kernel >= 2 ? 0ull : pl.n_chunks64;
     return DBDE_HIP_OK;
 }
@@ -784,16 +827,10 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
             n_chunks64 < (1ull << 31) && !(ctx->exp_flags & 32u)) {
             EncParams q = enc_params(ctx, g, W, H, n_frames, 2u, cpf2, 0u, reinterpret_cast<const uint8_t *>(d_images), d_out,
                                      slot_stride, first_index, d_frame_offsets, d_frame_bytes);
-            const size_t lb_need = (16 + 8 * (size_t)q.n_chunks + 15) & ~(size_t)15;
-            const size_t had = ctx->lb_bytes;
-            int rc = grow(ctx, ctx->lb, ctx->lb_bytes, lb_need, 1, true);
-            if (rc) return rc;
-            if (ctx->lb_bytes != had) ctx->lb_fresh = true;
             const bool aligned_out = (reinterpret_cast<uintptr_t>(d_out) & 7u) == 0 && g.T % 8 == 0 && slot_stride % 8 == 0;
             span_begin(ctx, 0);
-            HIP_TRY(ctx, hipMemsetAsync(ctx->lb, 0, lb_need, ctx->stream));
-            q.ctrl = reinterpret_cast<uint32_t *>(ctx->lb);
-            q.state = reinterpret_cast<unsigned long long *>(ctx->lb + 16);
+            int rc = attach_lookback(ctx, q, q.n_chunks, false);
+            if (rc) return rc;
             HIP_TRY(ctx, launch_encode16_fast(q, aligned_out, ctx->stream));
             span_end(ctx);
             return DBDE_HIP_OK;
@@ -1065,7 +1102,16 @@ int dbde_hip_diag_read(dbde_hip_ctx *ctx, uint64_t out[16]) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DBDE_HIP_OK;
 }
-
+#ifdef DBDE_DIAG
+// [1024][16] u64: wave 0's wall clock (10 ns) at the points of a persistent-encoder workgroup's life (encode_kernel).
+int dbde_hip_diag_trace_read(dbde_hip_ctx *ctx, uint64_t *out, size_t n_u64) {
+    if (!ctx || n_u64 > 16 * 1024) return DBDE_HIP_ERR_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->diag + 16, 8 * n_u64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->diag + 16, 0, 8 * 16 * 1024, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DBDE_HIP_OK;
+}
+#endif
 
 int dbde_hip_timing_enable(dbde_hip_ctx *ctx, int on) {
     if (!ctx) return DBDE_HIP_ERR_ARG;

@@ -74,6 +74,12 @@ constexpr unsigned long long kStAgg = 1ull << 62, kStInc = 2ull << 62, kStPoison
 // floor(2^32 / d) for the kernels' div_magic (d = 1: 2^32 - 1, which the one correction step absorbs).
 inline uint32_t div_magic_of(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
 
+#ifndef DBDE_CTRL_SLOT_WORDS
+#define DBDE_CTRL_SLOT_WORDS 64                 // u32 between two counters of the persistent encoder's control words: a 256-byte slot each (A/B: 4 KB slots measured the same)
+#endif
+constexpr uint32_t kEncCtrlWords = 2 * 16 * DBDE_CTRL_SLOT_WORDS + 1024;   // u32 per set of control words: 16 arrival + 16 tail-ticket counters, a slot each, + the rest
+constexpr uint32_t kEncMaxGrid = 4096;          // workgroups the mode flags have room for (dbde_capi.cpp: the look-back block's header)
+
 struct EncParams {
     const uint8_t *images;         // n_frames * W*H
     uint8_t *out;
@@ -82,8 +88,11 @@ struct EncParams {
     const uint64_t *indices;       // optional [n_frames]
     const uint64_t *elapsed_ns;    // optional [n_frames]
     uint64_t first_index;
-    unsigned long long *state;     // [n_chunks] look-back records, zeroed before the launch
-    uint32_t *ctrl;                // [1] scanner claim, [2] arrivals + tickets, [3] claim mode; zeroed before the launch
+    unsigned long long *state;     // [n_chunks] look-back records: no AGG / INC record when the launch starts (each is cleared by its reader)
+    uint32_t *ctrl;                // this launch's control words (kEncCtrlWords u32: group arrival / tail-ticket counters, mode, ticket counter; dbde_kernels.hip), zero when the launch starts
+    uint32_t *ctrl_next;           // the NEXT launch's set (the host alternates between two): cleared by the scanner
+    uint32_t *mode_flags;          // [grid] one word per workgroup: launch_epoch << 2 | claim mode, written by whoever settles the mode
+    uint32_t launch_epoch;         // 1 .. 2^30 - 1: tag of THIS persistent launch's mode flags (never cleared between launches)
     uint32_t *sticky;              // context-wide failure word, OR-ed on look-back time-out
     uint64_t slot_stride;          // 0 = frames concatenated
     uint64_t frame_pixels;         // W*H: BYTES of one frame's image (2 W H for launch_encode16_fast)
@@ -94,6 +103,7 @@ struct EncParams {
     // tile row (the last lane of a row holds one tile when w is odd); a chunk is 512 consecutive pairs in stream
     // order, wherever they fall.  lanes_per_row == 0: plain runs of 1024 tiles (w even: pairs never straddle).
     uint32_t lanes_per_row;
+    uint32_t pairs_per_wave;       // 64, or 63: dword-aligned fetches, a wave's 64th lane only feeds the 63rd (kInRaw4, dbde_kernels.hip)
     uint32_t magic_w, magic_cpf, magic_lpr;   // div_magic_of(w), (chunks_per_frame), (lanes_per_row): divisions by launch constants
     uint32_t last_frame;           // n_frames - 1: no pixel load reaches past the end of that frame
     uint32_t flags;                // bit 0: force ticket mode (A/B measurements); bit 6 (tests): small launches, odd chunks publish nothing

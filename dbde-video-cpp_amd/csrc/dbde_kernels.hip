@@ -364,6 +364,10 @@ __device__ __forceinline__ bool wait_inc(const u64a *state, uint32_t c, uint32_t
         if (st == 2u) {
             inf_incl = (uint32_t)((w >> 32) & 0x3FFFFFFFull);
             glob_incl = (uint32_t)w;
+            // The record has done its work (the scanner never looks below the record it is converting, nobody else
+            // reads this one): it is handed back clean, so that the next launch finds zeros without a memset in front
+            // of it -- that memset and its boundary were 8-10 us of every encode launch.
+            __hip_atomic_store(const_cast<u64a *>(&state[c]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
         if (st == 3u) return false;
@@ -396,6 +400,15 @@ __device__ __forceinline__ bool wait_inc(const u64a *state, uint32_t c, uint32_t
 // published without waiting on anything, the scanner is a running workgroup by construction:
 // the smallest unfinished chunk can always finish.
 constexpr int kEncWaves = kEncChunkTiles / 128;                  // two tiles per lane
+// control words of a persistent launch (EncParams::ctrl, a set of kCtrlWords u32, zero when the launch starts)
+// Sixteen arrival counters and sixteen tail-ticket counters (workgroup b uses counter b % 16), each ALONE in a 256-byte
+// slot: read-modify-writes to one 64-byte line retire one after the other whichever word they address (16 counters side
+// by side in one line measured no better than one counter: the first arrival number came back after 4.5 .. 13 us).
+constexpr uint32_t kEncGroups = 16, kCtrlSlot = DBDE_CTRL_SLOT_WORDS;   // (slot stride in u32)
+constexpr uint32_t kCtrlArrive = 0, kCtrlTail = kEncGroups * kCtrlSlot, kCtrlVerdict = 2u * kEncGroups * kCtrlSlot,
+                   kCtrlTickets = kCtrlVerdict + 2u /* u64, 8-byte aligned */;
+constexpr uint32_t kVerdictTimeout = 0x100u;                     // verdict word: groups complete in 7:0, this bit = somebody timed out
+static_assert(kCtrlTickets + 2u <= kEncCtrlWords, "control words do not fit their set");
 constexpr int kEncThreads = 64 * kEncWaves;
 constexpr uint32_t kWaveWords = 128 * 8;                         // 1024 U64 = 8 KiB per wave
 
@@ -405,12 +418,17 @@ struct EncShared {
     uint32_t lb[2][4];                       // [parity] {in-frame prefix, launch prefix, ok, next chunk id}
     uint32_t acc[2];                         // [parity] arrivals << 24 | sum of the waves' totals
     uint32_t boot[2];                        // role / first two chunk ids
+    uint32_t claim[2];                       // ticket mode: the first chunk's id
+#ifdef DBDE_DIAG
+    uint64_t dg[2];
+#endif
 };
 
 struct ChunkRef {
     uint32_t c, f, cf, t0;     // t0: stream index of the lane's first tile
     uint32_t ty, tx;           // its tile row and column
     bool valid, hasA, hasB;
+    bool loads;                // the lane fetches pixels at (ty, tx): hasA, or (kInRaw4) the wave's 64th lane, which only feeds lane 62
 };
 
 template <int PIX = 1>
@@ -425,18 +443,24 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
         k.t0 = k.cf * (kEncChunkTiles / 2u) + (uint32_t)tidw;
         k.hasA = k.hasB = k.valid && k.t0 < p.T;
         k.ty = div_magic(k.t0, p.w, p.magic_w, k.tx);
+        k.loads = k.hasA;
     } else if (p.lanes_per_row == 0u) {     // plain: 1024 consecutive tiles
         k.t0 = k.cf * kEncChunkTiles + 2u * (uint32_t)tidw;
         k.hasA = k.valid && k.t0 < p.T;
         k.hasB = k.valid && k.t0 + 1u < p.T;
         k.ty = div_magic(k.t0, p.w, p.magic_w, k.tx);
+        k.loads = k.hasA;
     } else {                                // the lane's pair: tile row = pair / lanes_per_row
-        const uint32_t pair = k.cf * (kEncChunkTiles / 2u) + (uint32_t)tidw;
+        // pairs_per_wave = 64: 512 consecutive pairs per chunk.  63 (kInRaw4): a wave OWNS 63 consecutive pairs and its
+        // 64th lane fetches the pair after them -- the first pair of the next wave -- for the sake of lane 62 alone
+        const uint32_t ppw = p.pairs_per_wave, lane = (uint32_t)tidw & 63u;
+        const uint32_t pair = k.cf * (ppw * (uint32_t)(kEncChunkTiles / 128u)) + ((uint32_t)tidw >> 6) * ppw + lane;
         uint32_t j;
         k.ty = div_magic(pair, p.lanes_per_row, p.magic_lpr, j);
         k.tx = 2u * j;
         k.t0 = k.ty * p.w + k.tx;
-        k.hasA = k.valid && k.ty < p.h;
+        k.loads = k.valid && k.ty < p.h;
+        k.hasA = k.loads && lane < ppw;
         k.hasB = k.hasA && k.tx + 1u < p.w;
     }
     return k;
@@ -452,7 +476,62 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
 //   kInBytes: images narrower than 16 pixels (byte by byte).
 // A template parameter, not a run-time branch: the number of loads a step issues must be static for them to
 // stay in flight.
-constexpr int kInFast = 0, kInRaw = 1, kInBytes = 2;
+//   kInRaw4 : kInRaw with every fetch moved down to a DWORD boundary (round 4).  A 16-byte load at an odd address runs at
+//             0.87 of the rate of one at ANY even address (profiles/read_align_probe.hip, 1921 wide: 5.99 against
+//             6.89 TB/s; rows that are merely 2-byte aligned already read at the full rate), and odd widths put seven
+//             of every eight image rows at odd addresses.  A lane fetches the 16 bytes from `address & ~3`; the b = address & 3
+//             bytes it is then short of at the top are the first bytes of the NEXT lane's fetch (same image row, same b):
+//             one DPP move (wave_shl:1) and four v_alignbyte_b32 per image row put the lane's 16 bytes back together when
+//             the registers are consumed (load_fixup_generic).  The wave's last lane has no next lane, so a wave owns 63
+//             pairs and its 64th lane fetches the pair after them (chunk_ref).  The last pair of a tile row is followed
+//             by the next tile row's first pair, whose bytes are not its continuation: the host takes this form only
+//             when the bytes such a lane is short of lie behind column W (EncPlan), where they are padding anyway.
+//             Image rows whose fetches must not move -- the batch's last image row, whose last fetch is moved LEFT to
+//             end with the buffer, and a first row that would start in front of it -- are fetched as kInRaw does, by
+//             the whole wave (a wave-uniform vote, taken again when the registers are consumed).
+constexpr int kInFast = 0, kInRaw = 1, kInBytes = 2, kInRaw4 = 3;
+
+// kInRaw4: which of a chunk's eight fetch rows must stay where they are, for the whole wave (bit r: row r) -- the batch's
+// last image row when the wave holds its moved-left last fetch, and the batch's very first fetch when moving it down
+// would start in front of the caller's buffer.  One vote per chunk in the common case (nobody has such a fetch); the
+// answer is wave-uniform, taken in front of the loads (no control flow between them, tests/test_kernel_listing.py).
+__device__ __forceinline__ uint32_t raw4_natural_rows(const EncParams &p, const ChunkRef &k, uint32_t ty, uint32_t tx, bool at_end) {
+    const bool first = k.f == 0u && ty == 0u && tx == 0u && ((uint32_t)reinterpret_cast<uintptr_t>(p.images) & 3u) != 0u;
+    uint32_t rows = 0u;
+    if (__any((int)(at_end || first))) {
+        const int rclamp = p.H - 1 - 8 * (int)ty;     // rows from here on repeat the image's last row
+        const uint32_t m = (at_end && rclamp <= 7 ? (0xFFu << (rclamp < 0 ? 0 : rclamp)) & 0xFFu : 0u) | (first ? 1u : 0u);
+#pragma unroll
+        for (int r = 0; r < 8; r++) rows |= __any((int)((m >> r) & 1u)) ? 1u << r : 0u;
+    }
+    return __builtin_amdgcn_readfirstlane(rows);
+}
+
+// The eight fetch rows of a kInRaw4 lane: where each fetch would naturally start (byte offset in the frame; a frame has
+// fewer than 2^30 pixels, so 32 bits and ONE multiplication per chunk) and by how many bytes (0..3) it is moved down to a
+// dword boundary.  Worked out twice, when the loads are issued and when their registers are consumed, from the same
+// inputs: the kernel sits at its VGPR limit and carries nothing from one to the other.
+struct Raw4Rows {
+    uint32_t off0, off_max, base_lo, nat_rows;
+    int dx_end;
+    __device__ __forceinline__ uint32_t row(const EncParams &p, int r, uint32_t &off) const {
+        uint32_t o = off0 + (uint32_t)r * (uint32_t)p.W;
+        o = o < off_max ? o : off_max;                           // rows below the image repeat its last row
+        const bool nat = (nat_rows >> r) & 1u;                   // (wave-uniform)
+        if (nat) o = (uint32_t)((int)o + (o == off_max ? dx_end : 0));   // the moved-left fetch of the batch's last row
+        off = o;
+        return nat ? 0u : (base_lo + o) & 3u;
+    }
+};
+__device__ __forceinline__ Raw4Rows raw4_rows(const EncParams &p, const ChunkRef &k, const uint8_t *img, uint32_t ty, uint32_t tx, bool at_end) {
+    Raw4Rows rw;
+    rw.nat_rows = raw4_natural_rows(p, k, ty, tx, at_end);
+    rw.off0 = 8u * ty * (uint32_t)p.W + 8u * tx;
+    rw.off_max = (uint32_t)(p.H - 1) * (uint32_t)p.W + 8u * tx;
+    rw.base_lo = (uint32_t)reinterpret_cast<uintptr_t>(img);
+    rw.dx_end = at_end ? p.W - 16 - 8 * (int)tx : 0;
+    return rw;
+}
 
 // PIX == 2 (DBDE16, kInFast only): the lane's 16 bytes of a row are ONE tile's eight U16 pixels -- va holds the
 // left half (pixels 0..3) of each row, vb the right half; frame_pixels counts bytes there.
@@ -465,27 +544,38 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
         for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
     }
     const uint8_t *img = p.images + (size_t)k.f * p.frame_pixels;
-    if (IN_MODE == kInFast || IN_MODE == kInRaw) {
+    if (IN_MODE == kInFast || IN_MODE == kInRaw || IN_MODE == kInRaw4) {
+        constexpr bool RAW = IN_MODE == kInRaw || IN_MODE == kInRaw4;
         // No branch around the loads: a lane without tiles reads tile 0 of frame 0 and nobody looks
         // at the result.  With a conditional issue the compiler cannot know how many loads are in
         // flight and makes the statistics of the CURRENT chunk wait for these as well.
-        const uint32_t ty = k.hasA ? k.ty : 0u, tx = k.hasA ? k.tx : 0u;
+        const uint32_t ty = k.loads ? k.ty : 0u, tx = k.loads ? k.tx : 0u;
         const uint32_t x0 = (PIX == 2 ? 16u : 8u) * tx;   // byte column
         // kInRaw: the 16 bytes of a row's last lane run into the next image row -- harmless, those bytes are replaced by
         // the constant padding (load_fixup_generic) -- except in the last image row of the batch, where they would pass
         // the end of the caller's buffer: there, and only there, the fetch is moved left to END at the row's last pixel
-        const bool at_end = IN_MODE == kInRaw && k.f == p.last_frame && x0 + 16u > (uint32_t)p.W;
+        const bool at_end = RAW && k.f == p.last_frame && x0 + 16u > (uint32_t)p.W;
+        Raw4Rows rw;
+        if (IN_MODE == kInRaw4) rw = raw4_rows(p, k, img, ty, tx, at_end);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            int yy = 8 * (int)ty + r;
-            yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
-            const uint32_t xr = at_end && yy == p.H - 1 ? (uint32_t)p.W - 16u : x0;
-            const uint8_t *src = img + (size_t)yy * (size_t)(PIX * p.W) + xr;
+            const uint8_t *src;
+            if (IN_MODE == kInRaw4) {
+                uint32_t off;
+                const uint32_t b = rw.row(p, r, off);
+                // (signed: the first fetch of a frame starts up to 3 bytes in front of it, in the frame before)
+                src = img + (ptrdiff_t)(int32_t)(off - b);
+            } else {
+                int yy = 8 * (int)ty + r;
+                yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
+                const uint32_t xr = at_end && yy == p.H - 1 ? (uint32_t)p.W - 16u : x0;
+                src = img + (size_t)yy * (size_t)(PIX * p.W) + xr;
+            }
             u32x4_t q;
             if (IN_MODE == kInFast) {
                 q = DBDE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(src))
                             : *reinterpret_cast<const u32x4_t *>(src);
-            } else {   // any byte alignment: global memory takes it, the compiler must be told
+            } else {   // any byte alignment (kInRaw4: dword aligned but for pinned rows): global memory takes it, the compiler must be told
                 typedef u32x4_t __attribute__((aligned(1))) u32x4_unaligned;
                 q = DBDE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(src))
                             : *reinterpret_cast<const u32x4_unaligned *>(src);
@@ -507,11 +597,28 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
 template <int IN_MODE>
 __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                                    uint32_t (&vb)[16]) {
-    if (IN_MODE != kInRaw) return;
+    if (IN_MODE != kInRaw && IN_MODE != kInRaw4) return;
     const uint32_t x0 = 8u * k.tx, W = (uint32_t)p.W;
-    const uint32_t rmA = !k.hasA ? 8u : (W - x0 < 8u ? W - x0 : 8u);          // valid columns of the two tiles
-    const uint32_t rmB = !k.hasB ? 8u : (W - x0 - 8u < 8u ? W - x0 - 8u : 8u);
-    const bool at_end = k.hasA && k.f == p.last_frame && x0 + 16u > W;
+    if (IN_MODE == kInRaw4) {
+        // every fetch had been moved down to a dword boundary (load_chunk): the lane's 16 bytes are bytes b .. b + 15 of its
+        // own four dwords followed by the next lane's first one (wave_shl:1 -- lane 63 receives nothing and owns no tile)
+        const uint32_t ty = k.loads ? k.ty : 0u, tx = k.loads ? k.tx : 0u;
+        const Raw4Rows rw = raw4_rows(p, k, p.images + (size_t)k.f * p.frame_pixels, ty, tx, k.f == p.last_frame && 8u * tx + 16u > W);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t off;
+            const uint32_t b = rw.row(p, r, off);
+            const uint32_t t0 = va[2 * r], t1 = va[2 * r + 1], t2 = vb[2 * r], t3 = vb[2 * r + 1];
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t0, 0x130, 0xF, 0xF, false);   // wave_shl:1
+            va[2 * r] = __builtin_amdgcn_alignbyte(t1, t0, b);
+            va[2 * r + 1] = __builtin_amdgcn_alignbyte(t2, t1, b);
+            vb[2 * r] = __builtin_amdgcn_alignbyte(t3, t2, b);
+            vb[2 * r + 1] = __builtin_amdgcn_alignbyte(n0, t3, b);
+        }
+    }
+    // the lane that holds a tile row's last tile: tile A when w is odd (the pair's second tile does not exist), else tile B
+    const bool last_lane = k.hasA && k.tx + 2u >= p.w;
+    const bool at_end = last_lane && k.f == p.last_frame && x0 + 16u > W;
     if (__any((int)at_end)) {   // (once per launch, in the workgroup that holds the batch's last tile row)
         const uint32_t sh = x0 + 16u - W;            // bytes the fetch was moved left: 1..15
 #pragma unroll
@@ -527,26 +634,27 @@ __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const Chu
             }
         }
     }
-    if (__all((int)(rmA == 8u && rmB == 8u))) return;
-    auto masks = [](uint32_t rm, uint32_t &m0, uint32_t &m1, uint32_t &sh, bool &from_hi) {
-        m0 = rm >= 4u ? 0xFFFFFFFFu : (1u << (8u * rm)) - 1u;                                   // valid bytes of the low dword
-        m1 = rm <= 4u ? 0u : (rm >= 8u ? 0xFFFFFFFFu : (1u << (8u * (rm - 4u))) - 1u);          // ... of the high dword
-        from_hi = rm > 4u;                                                                      // where the last valid pixel is
-        sh = 8u * ((rm - 1u) & 3u);
-    };
-    uint32_t a0, a1, ash, b0, b1, bsh;
-    bool ahi, bhi;
-    masks(rmA, a0, a1, ash, ahi);
-    masks(rmB, b0, b1, bsh, bhi);
+    // The constant padding.  Only a tile row's LAST tile can be partial, it has the same W - 8 (w - 1) valid columns in
+    // every tile row, and it is the lane's tile A or B by the parity of w: the masks are launch constants (scalar), one
+    // tile is patched, not two (round 3 worked out per-lane masks for both tiles: twice the work in every wave that holds
+    // a row end -- more than half of them at 241 tiles across).
+    const uint32_t rm = W - 8u * (p.w - 1u);          // 1..8
+    if (rm == 8u || !__any((int)last_lane)) return;
+    const uint32_t m0 = rm >= 4u ? 0xFFFFFFFFu : (1u << (8u * rm)) - 1u;                 // valid bytes of the low dword
+    const uint32_t m1 = rm <= 4u ? 0u : (1u << (8u * (rm - 4u))) - 1u;                   // ... of the high dword (rm < 8)
+    const bool from_hi = rm > 4u;                                                        // where the last valid pixel is
+    const uint32_t sh = 8u * ((rm - 1u) & 3u);
+    const uint32_t k0 = last_lane ? m0 : 0xFFFFFFFFu, k1 = last_lane ? m1 : 0xFFFFFFFFu;   // (other lanes keep their bytes)
+    auto patch = [&](uint32_t (&v)[16]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint32_t fa = (((ahi ? va[2 * r + 1] : va[2 * r]) >> ash) & 0xFFu) * 0x01010101u;
-        const uint32_t fb = (((bhi ? vb[2 * r + 1] : vb[2 * r]) >> bsh) & 0xFFu) * 0x01010101u;
-        va[2 * r] = (va[2 * r] & a0) | (fa & ~a0);
-        va[2 * r + 1] = (va[2 * r + 1] & a1) | (fa & ~a1);
-        vb[2 * r] = (vb[2 * r] & b0) | (fb & ~b0);
-        vb[2 * r + 1] = (vb[2 * r + 1] & b1) | (fb & ~b1);
-    }
+        for (int r = 0; r < 8; r++) {
+            const uint32_t f = (((from_hi ? v[2 * r + 1] : v[2 * r]) >> sh) & 0xFFu) * 0x01010101u;   // the last valid pixel, repeated (dbde_util.cpp:116-128)
+            v[2 * r] = (v[2 * r] & k0) | (f & ~k0);
+            v[2 * r + 1] = (v[2 * r + 1] & k1) | (f & ~k1);
+        }
+    };
+    if (p.w & 1u) patch(va);
+    else patch(vb);
 }
 
 // One tile row -> 8*d-bit integer with two v_dot4_u32_u8 per 4 pixels (weights 1, 2^d);
@@ -730,62 +838,119 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     __shared__ __attribute__((aligned(16))) EncShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef DBDE_DIAG
+    const uint64_t dg_entry = (uint64_t)wall_clock64();
     if (tid == 0) {   // when the launch's workgroups start (wall clock, 10 ns): earliest as a max of the complement
-        const unsigned long long t = wall_clock64();
+        const unsigned long long t = dg_entry;
         atomicMax(&p.diag[11], ~t);
         atomicMax(&p.diag[12], t);
     }
 #endif
 
-    // The first workgroup to get here becomes the scanner: one of its waves runs the in-order
-    // scan, the others retire.  Being first to run, it is a running workgroup by construction.
+    // Roles, ranks and the claim mode.  Read-modify-writes on ONE address retire at about 15 ns each on this part, whoever
+    // issues them (in-kernel timeline, -DDBDE_DIAG): round 3's prologue -- 512 arrivals on one counter, then 511 pollers on
+    // one word until all had been seen -- held every launch for 22 us with a single chunk of loads in flight, and handing
+    // the first rounds out as tickets from one counter cost as much again (12-14 us steps instead of 9).  So:
+    //   * arrivals are counted in 16 GROUP counters (workgroup b adds to counter b % 16: 32 contenders per address) and
+    //     the value drawn gives the arrival number R = v * 16 + b % 16 -- dense 0 .. G once everybody has arrived;
+    //   * R == 0 is the SCANNER (one of its waves runs the in-order scan, the others retire): the first of its group to
+    //     run, a running workgroup by construction.  Any other R encodes, with rank R - 1, and fetches chunk `rank` at once;
+    //   * the last arrival of a group bumps a second-level counter; whoever completes it has seen ALL G + 1 workgroups
+    //     running and settles the launch's mode -- STATIC strides (chunk = rank + k G, no atomics: only safe
+    //     when every encoding workgroup runs) -- and TELLS everybody: its 512 threads write one flag per workgroup
+    //     (tagged with the launch's epoch, so flags are never cleared).  A workgroup polls only its OWN flag;
+    //   * a flag that has not come after 20 us (oversubscribed device: somebody is not running) sets the time-out bit of
+    //     that second-level word -- whichever of the two read-modify-writes comes first decides -- and the verdict is TICKETS: every chunk id, the first included, is then drawn from one counter by a
+    //     workgroup that is running -- dense in draw order, forward progress whatever the dispatch order (a
+    //     single-address ticket per chunk costs 6-13 % at full speed, which is why it is the fallback).
     const uint32_t G = gridDim.x - 1u;              // workgroups that encode
+    const uint32_t n_grp = gridDim.x < kEncGroups ? gridDim.x : kEncGroups, grp = blockIdx.x % kEncGroups;
+    const uint32_t tag = p.launch_epoch << 2;
+    u64a *const tickets = reinterpret_cast<u64a *>(p.ctrl + kCtrlTickets);
     if (tid == 0) {
-        const uint32_t is_scanner = atomicCAS(&p.ctrl[1], 0u, 1u) == 0u ? 1u : 0u;
-        sh.boot[1] = is_scanner;
-        // every encoding workgroup's FIRST chunk is its arrival rank: dense, in start order
-        sh.boot[0] = is_scanner ? 0u : atomicAdd(&p.ctrl[2], 1u);
+        // (a context whose sticky failure word is set has records in an unknown state: its launches do nothing until
+        // dbde_hip_sync has reported the failure and the host has cleared the workspace)
+        // (a plain load: the word was last written by an EARLIER kernel, so the caches are good for it -- as an agent-scope
+        // atomic load it went to the memory side, where 512 reads of one address queued up for 13 us)
+        const uint32_t dead = *p.sticky;
+        const uint32_t v = atomicAdd(&p.ctrl[kCtrlArrive + grp * kCtrlSlot], 1u);
+#ifdef DBDE_DIAG
+        sh.dg[0] = v == 0xFFFFFFFFu ? 0ull : (uint64_t)wall_clock64();   // (the arrival number has come back)
+#endif
+        uint32_t tell = 0u;
+        if (v + 1u == (gridDim.x - grp + kEncGroups - 1u) / kEncGroups) {               // the last of its group ...
+            const uint32_t old = atomicAdd(&p.ctrl[kCtrlVerdict], 1u);
+            if (!(old & kVerdictTimeout) && (old & 0xFFu) + 1u == n_grp)                  // ... and of the groups, in time
+                tell = (p.flags & 1u) ? 2u : 1u;
+        }
+        sh.boot[0] = dead ? 0xFFFFFFFFu : v * kEncGroups + grp;
+        sh.boot[1] = tell;
         sh.acc[0] = 0; sh.acc[1] = 0;
     }
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane(sh.boot[1]) != 0u) {
-        if (wave == 0) scanner_loop<ALIGNED_OUT>(p, lane);
+    const uint32_t arrival = __builtin_amdgcn_readfirstlane(sh.boot[0]);
+    if (arrival == 0xFFFFFFFFu) return;
+    {
+        const uint32_t tell = __builtin_amdgcn_readfirstlane(sh.boot[1]);
+        if (tell)
+            for (uint32_t i = (uint32_t)tid; i < gridDim.x; i += (uint32_t)kEncThreads)
+                __hip_atomic_store(&p.mode_flags[i], tag | tell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (arrival == 0u) {
+        if (wave == 0) {
+            // the control words of the NEXT launch (the host alternates between two sets) are cleared here: no memset
+            if (lane < (int)kEncGroups) { p.ctrl_next[kCtrlArrive + lane * kCtrlSlot] = 0u; p.ctrl_next[kCtrlTail + lane * kCtrlSlot] = 0u; }
+            if (lane < 4) p.ctrl_next[kCtrlVerdict + lane] = 0u;
+            scanner_loop<ALIGNED_OUT>(p, lane);
+        }
         return;
     }
-    const uint32_t rank = __builtin_amdgcn_readfirstlane(sh.boot[0]);
+    const uint32_t rank = arrival - 1u;
     ChunkRef cur = chunk_ref<PIX>(p, rank, tid);
     uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-    load_chunk<IN_MODE, true, PIX>(p, cur, r0a, r0b);          // in flight while the mode is agreed below
+    load_chunk<IN_MODE, true, PIX>(p, cur, r0a, r0b);          // in flight while the mode arrives
     __syncthreads();   // sh.boot is reused below
-
-    // How later chunks are claimed.  STATIC (chunk = rank + k*G, no atomics) is only safe when
-    // every one of the G encoding workgroups is running at the same time; that is proven, not
-    // assumed: all G have arrived before anyone left.  One CAS makes the decision for the whole
-    // launch; if the arrivals do not complete within ~20 us (oversubscribed device, occupancy
-    // over-estimated), the decision is TICKETS (the arrival counter keeps counting: chunk ids are
-    // dense in draw order), which needs nothing but running workgroups.  (A single-address ticket per chunk costs 6-13 % at full speed.)
     if (tid == 0) {
-        uint32_t mode = 0;
+        uint32_t mode = 0u, tell = 0u;
         const uint64_t t0 = wall_clock64();
-        // one chunk per workgroup at most (n_chunks <= G): there is nothing to agree on
-        if (p.n_chunks <= G) mode = 1u;
-        while (!mode) {
-            mode = __hip_atomic_load(&p.ctrl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mode) break;
-            const uint32_t arrived = __hip_atomic_load(&p.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrived >= G && !(p.flags & 1u)) atomicCAS(&p.ctrl[3], 0u, 1u);
-            else if ((p.flags & 1u) || wall_clock64() - t0 > 2000ull) atomicCAS(&p.ctrl[3], 0u, 2u);
-            else __builtin_amdgcn_s_sleep(2);
+#ifdef DBDE_DIAG
+        sh.dg[1] = t0;   // (first chunk's loads issued, barrier passed: the poll starts)
+#endif
+        for (;;) {
+            const uint32_t f = __hip_atomic_load(&p.mode_flags[arrival], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((f & ~3u) == tag && (f & 3u)) { mode = f & 3u; break; }
+            if (wall_clock64() - t0 > 2000ull) {   // 20 us: not everybody is running
+                const uint32_t old = atomicOr(&p.ctrl[kCtrlVerdict], kVerdictTimeout);
+                if (old & kVerdictTimeout) mode = 2u;                                     // somebody else timed out first (and tells)
+                else if ((old & 0xFFu) == n_grp) mode = (p.flags & 1u) ? 2u : 1u;         // everybody HAS arrived: the flag is on its way
+                else { mode = 2u; tell = 2u; }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
         }
-        sh.boot[1] = mode;
-        sh.boot[0] = mode == 1u ? rank + G : atomicAdd(&p.ctrl[2], 1u);   // tickets continue the arrival counter: ids stay dense
+        sh.boot[1] = mode | (tell << 8);
+        if (mode == 1u) {
+            sh.boot[0] = rank + G;
+        } else {   // tickets: two draws -- the chunk fetched above is dropped, ids are dense in draw order from 0
+            const u64a t = atomicAdd(tickets, 2ull);
+            sh.claim[0] = (uint32_t)t;
+            sh.boot[0] = (uint32_t)t + 1u;
+        }
     }
     __syncthreads();
-    const bool static_mode = __builtin_amdgcn_readfirstlane(sh.boot[1]) == 1u;
+    const bool static_mode = (__builtin_amdgcn_readfirstlane(sh.boot[1]) & 0xFFu) == 1u;
+    if ((__builtin_amdgcn_readfirstlane(sh.boot[1]) >> 8) != 0u)   // this workgroup settled it by time-out: everybody is told
+        for (uint32_t i = (uint32_t)tid; i < gridDim.x; i += (uint32_t)kEncThreads)
+            __hip_atomic_store(&p.mode_flags[i], tag | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!static_mode) {
+        cur = chunk_ref<PIX>(p, __builtin_amdgcn_readfirstlane(sh.claim[0]), tid);
+        load_chunk<IN_MODE, true, PIX>(p, cur, r0a, r0b);
+    }
     // Static strides leave the launch's tail to chance: workgroups do not run at the same speed (the first leaves 30-40 us
     // before the last on a 1-4 ms launch).  The last kTailRounds rounds of chunk ids -- everything from s_static on, the
-    // same boundary for every workgroup -- are therefore drawn as tickets (ctrl[0]) even in static mode: ids stay dense, a
-    // ticket belongs to a running workgroup, and a fast workgroup simply draws more of them.
+    // same boundary for every workgroup -- are therefore drawn as tickets even in static mode: a ticket belongs to a
+    // running workgroup, and a fast workgroup simply draws more of them.  Sixteen counters again, one per group: group g
+    // hands out the ids s_static + 16 t + g, so the 32 workgroups of a group level out among themselves and no counter
+    // sees more than 32 draws per round (511 draws per round on one counter take longer than the round).
     // (A workgroup's first two chunks, rank and rank + G, are always static: the boundary lies at 2 G or above.)
     constexpr uint32_t kTailRounds = 3;
     const uint32_t full_rounds = p.n_chunks / G;
@@ -798,6 +963,9 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
 #ifdef DBDE_DIAG
     uint64_t dg_wait = 0, dg_nwait = 0, dg_bar = 0, dg_npoll = 0, dg_first = 0;
     const uint64_t dg_k0 = __builtin_amdgcn_s_memtime();
+    // per-workgroup timeline (wall clock, 10 ns): [0] entry, [1] mode agreed, [2..7] end of steps 0..5, [8] first step that
+    // had no chunk left to prefetch, [9] exit, [10] steps run, [11] chunks packed
+    uint64_t tr[12] = {dg_entry, (uint64_t)wall_clock64(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     // One pipeline step.  `ca/cb` hold the pixels of cur (loaded one step ago), `na/nb` receive
@@ -838,9 +1006,9 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
                 }
                 uint32_t tnew = 0xFFFFFFFFu;   // id of the chunk after nxt
                 if (nxt.valid) {
-                    if (!static_mode) tnew = atomicAdd(&p.ctrl[2], 1u);
+                    if (!static_mode) tnew = (uint32_t)atomicAdd(tickets, 1ull);
                     else if (nxt.c + G < s_static) tnew = nxt.c + G;
-                    else tnew = s_static + atomicAdd(&p.ctrl[0], 1u);
+                    else tnew = s_static + atomicAdd(&p.ctrl[kCtrlTail + grp * kCtrlSlot], 1u) * n_grp + grp;
                 }
                 sh.lb[par][0] = inf;
                 sh.lb[par][1] = glob;
@@ -848,6 +1016,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
                 sh.lb[par][3] = tnew;
             }
         };
+        auto load_nxt = [&]() __attribute__((always_inline)) { load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb); };
         // ---- statistics of cur (dbde_util.cpp:30-68), offsets inside the wave, AGG ---------------------------
         uint32_t mnA, mxA, mnB, mxB, dA, dB, incl, wtot;
         auto statistics = [&]() __attribute__((always_inline)) {
@@ -856,6 +1025,9 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
                 dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
                 mnB = 0u; mxB = 0u; dB = 0u;
             } else {
+                // the any-geometry forms sit at the register limit: the lane's place in the chunk is worked out again here
+                // (ten VALU) instead of being carried from the step that issued the loads
+                if (IN_MODE == kInRaw4 || IN_MODE == kInRaw) cur = chunk_ref<PIX>(p, cur.c, tid);
                 load_fixup_generic<IN_MODE>(p, cur, ca, cb);
                 tile_minmax(ca, mnA, mxA);
                 tile_minmax(cb, mnB, mxB);
@@ -886,19 +1058,19 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         // that remains is the in-order prefix itself, not the position of the poll.
 #if DBDE_POLL == 0
         mailbox();
-        load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
+        load_nxt();
         statistics();
 #elif DBDE_POLL == 1
-        load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
+        load_nxt();
         statistics();
         mailbox();
 #else
         if (wave == 0) {
             statistics();
             mailbox();
-            load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
+            load_nxt();
         } else {
-            load_chunk<IN_MODE, true, PIX>(p, nxt, na, nb);
+            load_nxt();
             statistics();
         }
 #endif
@@ -920,6 +1092,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
             prev.valid = false;
             cur.valid = cur.hasA = cur.hasB = false;
             nxt.valid = nxt.hasA = nxt.hasB = false;
+            cur.c = nxt.c = 0xFFFFFFFFu;
         }
         uint32_t wbase = 0, cur_total = 0;
 #pragma unroll
@@ -962,6 +1135,16 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
+#ifdef DBDE_DIAG
+        {
+            const uint64_t t_now = (uint64_t)wall_clock64();
+#pragma unroll
+            for (int i_ = 0; i_ < 4; i_++) if (tr[10] == (uint64_t)i_) tr[2 + i_] = t_now;
+            if (!nxt.valid && !tr[8]) tr[8] = t_now;
+        }
+        tr[10]++;
+        tr[11] += cur.valid ? 1u : 0u;
+#endif
         // ---- rotate the pipeline -------------------------------------------------------------------
         prev = cur;
         prev_meta = PIX == 2 ? dA | (mnA << 16) : dA | (dB << 8) | (mnA << 16) | (mnB << 24);
@@ -1000,11 +1183,18 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         atomicAdd(&p.diag[9], dg_npoll);
         atomicAdd(&p.diag[10], dg_first);
         atomicMax(&p.diag[14], wall_clock64());   // ... and when the last one leaves
+        tr[9] = (uint64_t)wall_clock64();
+        if (blockIdx.x < 1024u)
+            for (int i = 0; i < 12; i++) p.diag[16 + 16 * blockIdx.x + i] = tr[i];
+            p.diag[16 + 16 * blockIdx.x + 6] = sh.dg[0];
+            p.diag[16 + 16 * blockIdx.x + 7] = sh.dg[1];
     }
 #endif
 }
 
-static int in_mode_of(const EncParams &p, bool fast_in) { return fast_in ? kInFast : (p.lanes_per_row ? kInRaw : kInBytes); }
+static int in_mode_of(const EncParams &p, bool fast_in) {
+    return fast_in ? kInFast : (p.lanes_per_row ? (p.pairs_per_wave == 63u ? kInRaw4 : kInRaw) : kInBytes);
+}
 
 // DBDE16 through the same persistent kernel (PIX = 2): W % 8 == 0 and a 16-byte aligned base, 512 tiles per chunk,
 // EncParams::frame_pixels in BYTES.  Other geometries and small launches stay with dbde16_kernels.hip.
@@ -1026,6 +1216,8 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
         case kInRaw * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInRaw, true>), grid, block, 0, s, p); break;
         case kInRaw * 2 + 0: hipLaunchKernelGGL((encode_kernel<kInRaw, false>), grid, block, 0, s, p); break;
         case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInBytes, true>), grid, block, 0, s, p); break;
+        case kInRaw4 * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInRaw4, true>), grid, block, 0, s, p); break;
+        case kInRaw4 * 2 + 0: hipLaunchKernelGGL((encode_kernel<kInRaw4, false>), grid, block, 0, s, p); break;
         default: hipLaunchKernelGGL((encode_kernel<kInBytes, false>), grid, block, 0, s, p); break;
     }
     return hipGetLastError();
@@ -1179,6 +1371,8 @@ hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_ou
         case kInRaw * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInRaw, true>), grid, block, 0, s, p); break;
         case kInRaw * 2 + 0: hipLaunchKernelGGL((encode_small_kernel<kInRaw, false>), grid, block, 0, s, p); break;
         case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInBytes, true>), grid, block, 0, s, p); break;
+        case kInRaw4 * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInRaw4, true>), grid, block, 0, s, p); break;
+        case kInRaw4 * 2 + 0: hipLaunchKernelGGL((encode_small_kernel<kInRaw4, false>), grid, block, 0, s, p); break;
         default: hipLaunchKernelGGL((encode_small_kernel<kInBytes, false>), grid, block, 0, s, p); break;
     }
     return hipGetLastError();

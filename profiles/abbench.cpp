@@ -133,6 +133,10 @@ int main(int argc, char **argv) {
         fn_diag dr = (fn_diag)dlsym(h, "dbde_hip_diag_read");
         uint64_t junk[16];
         if (dr) dr(c, junk);
+        using fn_trace0 = int (*)(ctx *, uint64_t *, size_t);
+        fn_trace0 trd0 = (fn_trace0)dlsym(h, "dbde_hip_diag_trace_read");
+        static uint64_t junk_tr[16 * 1024];
+        if (trd0) trd0(c, junk_tr, 16 * 1024);
     }
     timed = true;
     auto t0 = std::chrono::steady_clock::now();
@@ -151,6 +155,25 @@ int main(int argc, char **argv) {
                     "scanner per launch: %.0f rounds, %.1f %% idle, %.1f records/round, %.0f cyc\n", tag, content,
                     d[2] / wg, d[0] / wg, 100.0 * d[0] / d[2], d[1] / wg, (double)d[9] / (d[1] ? d[1] : 1), 100.0 * d[10] / (d[1] ? d[1] : 1), d[7] / wg, 100.0 * d[7] / d[2],
                     (double)d[3] / steps, 100.0 * d[4] / (d[3] ? d[3] : 1), (double)d[6] / (d[3] ? d[3] : 1), (double)d[5] / steps);
+            using fn_trace = int (*)(ctx *, uint64_t *, size_t);
+            fn_trace trd = (fn_trace)dlsym(h, "dbde_hip_diag_trace_read");
+            if (trd && steps == 1) {   // per-workgroup timeline of the one timed launch: min / mean / max of each point, us after the first entry
+                static uint64_t tr[16 * 1024];
+                if (trd(c, tr, 16 * 1024) == 0) {
+                    uint64_t t0 = ~0ull; int n = 0;
+                    for (int g = 0; g < 1024; g++) if (tr[16 * g + 9]) { n++; if (tr[16 * g] < t0) t0 = tr[16 * g]; }
+                    static const char *nm[10] = {"entry", "mode agreed", "step 0 done", "step 1 done", "step 2 done", "step 3 done", "arrival number back", "poll starts", "last prefetch", "exit"};
+                    fprintf(stderr, "trace[%s]: %d encoding workgroups;", tag, n);
+                    for (int i = 0; i < 10; i++) {
+                        double mn = 1e30, mx = 0, sum = 0; int k = 0;
+                        for (int g = 0; g < 1024; g++) if (tr[16 * g + 9] && tr[16 * g + i]) { const double v = (double)(tr[16 * g + i] - t0) / 100.0; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; k++; }
+                        if (k) fprintf(stderr, " %s %.1f/%.1f/%.1f", nm[i], mn, sum / k, mx);
+                    }
+                    double smn = 1e30, smx = 0, cmn = 1e30, cmx = 0;
+                    for (int g = 0; g < 1024; g++) if (tr[16 * g + 9]) { const double a = (double)tr[16 * g + 10], b = (double)tr[16 * g + 11]; smn = a < smn ? a : smn; smx = a > smx ? a : smx; cmn = b < cmn ? b : cmn; cmx = b > cmx ? b : cmx; }
+                    fprintf(stderr, " | steps %.0f..%.0f, chunks %.0f..%.0f per workgroup (min/mean/max us)\n", smn, smx, cmn, cmx);
+                }
+            }
             if (d[11] && steps == 1) {   // one timed launch: when its workgroups started and the last one left (10 ns wall clock)
                 const double t0 = (double)(~d[11]);
                 fprintf(stderr, "diag[%s]: workgroups start within %.1f us, the last leaves %.1f us after the first start; a pair of steps takes "

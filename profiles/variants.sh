@@ -10,7 +10,13 @@ for spec in "$@"; do
     name=${spec%%=*}; flags=${spec#*=}; [ "$flags" == "$spec" ] && flags=""
     out=$ROOT/profiles/variants/$name
     mkdir -p $out
-    if [ "$name" == "r01" ]; then
+    if [ "${name#rev_}" != "$name" ]; then   # rev_<git revision>: the library as it was at that revision (same-box A/B against history)
+        tmp=$(mktemp -d)
+        git archive ${name#rev_} dbde-video-cpp_amd/csrc include | tar -x -C $tmp
+        make -s -C $tmp/dbde-video-cpp_amd/csrc
+        cp $tmp/dbde-video-cpp_amd/libdbde_hip.so $out/
+        rm -rf $tmp
+    elif [ "$name" == "r01" ]; then
         tmp=$(mktemp -d)
         git archive da16388 dbde-video-cpp_amd/csrc include | tar -x -C $tmp
         make -s -C $tmp/dbde-video-cpp_amd/csrc

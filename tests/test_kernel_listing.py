@@ -74,6 +74,8 @@ def pixel_load_groups(lines):
 
 PERSISTENT = ["_ZN4dbde13encode_kernelILi0ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0ELi1EEEvNS_9EncParamsE",
               "_ZN4dbde13encode_kernelILi1ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi1ELb0ELi1EEEvNS_9EncParamsE",
+              # any geometry, dword-aligned fetches (round 4)
+              "_ZN4dbde13encode_kernelILi3ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi3ELb0ELi1EEEvNS_9EncParamsE",
               # DBDE16 through the same kernel (PIX = 2: one 16-bit tile per lane, the same eight 16-byte loads per step)
               "_ZN4dbde13encode_kernelILi0ELb1ELi2EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0ELi2EEEvNS_9EncParamsE"]
 
@@ -83,8 +85,12 @@ def test_persistent_encoder_pixel_waits_are_exactly_the_loads_in_flight(listing,
     """Aligned widths (encode_kernel<0,*,1>), any geometry (<1,*,1>: BASELINE configs[3]'s kernel), DBDE16 (<0,*,2>)."""
     lines = function_body(listing, mangled)
     groups = pixel_load_groups(lines)
-    steady = [(a, b, w) for a, b, w in groups if w]   # the prologue's group meets a barrier first (drained behind it)
-    assert len(steady) == 2, f"expected the two unrolled pipeline steps, found {len(steady)} ({groups})"
+    # the prologue's groups come first: the first chunk's fetch meets a barrier (drained behind it); round 4's prologue
+    # fetches the first chunk a second time when the launch falls back to tickets (a group whose first wait is vmcnt(0)
+    # for the mode flag, not part of the loop).  The loop's two unrolled steps are the LAST two groups.
+    assert 2 <= len(groups) <= 4, groups
+    assert all(not w or w[0] == 0 for _, _, w in groups[:-2]), f"unexpected load group in front of the loop: {groups}"
+    steady = groups[-2:]
     for first_load, last, w in steady:
         assert w[:8] == [15, 14, 13, 12, 11, 10, 9, 8], (
             f"pixel waits are {w[:8]}: looser than 15..8 means younger stores are being counted on to retire in "

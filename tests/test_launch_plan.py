@@ -31,7 +31,13 @@ def test_baseline_configs():
     assert dv.decode_plan(2048, 2048, 1000)["image_mode"] == DIRECT
     # configs[3]: 1921x1081 -- any-geometry encoder, staged decode on chunks of two whole tile rows (2 x 241 tiles)
     e = dv.encode_plan(1921, 1081, 2048, slot_stride=2168320)
-    assert (e["kernel"], e["input_mode"], e["aligned_out"]) == (PERSISTENT, 1, 1)
+    # (round 4: dword-aligned fetches -- input mode 3 -- a wave owns 63 tile pairs: 8 x 63 x 2 tiles per chunk, 136 x 121 pairs)
+    assert (e["kernel"], e["input_mode"], e["aligned_out"], e["chunk_tiles"], e["chunks_per_frame"]) == (PERSISTENT, 3, 1, 1008, 33)
+    # rows that are dword aligned already, or whose last pair holds more than 13 columns, keep natural-position fetches
+    assert dv.encode_plan(1928, 1080, 2048)["input_mode"] == 1      # even addresses read at the full rate as they are
+    assert dv.encode_plan(1366, 768, 2048)["input_mode"] == 1
+    assert dv.encode_plan(1928, 1080, 2048, image_address=1)["input_mode"] == 3
+    assert dv.encode_plan(1935, 1080, 2048)["input_mode"] == 1      # last pair: 15 columns
     d = dv.decode_plan(1921, 1081, 2048)
     assert (d["image_mode"], d["threads"], d["chunk_tiles"], d["chunks_per_frame"]) == (STAGED, 256, 482, 68)
 

@@ -27,6 +27,7 @@ call); launched under torchrun it uses the ranks it is given.  Frames are sharde
 Rank 0 prints ONE JSON line.  `value` = frames all ranks round-tripped per second.
 """
 import argparse
+import copy
 import hashlib
 import json
 import os
@@ -516,20 +517,39 @@ def dry_run(args, world, rank, dist):
         time.sleep(0.001)
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     gathered = None
+    line = {"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "value": 0.0,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "none (dry run: launch contract only, no GPU work, not a measurement)",
+            "dry_run": True, "frames_of_rank0": [lo, hi], "gathered_bytes": None,
+            "config": {"workload": "dry run"}}
     if dist is not None:
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        seg = torch.full((100 + 7 * rank,), rank, dtype=torch.uint8)
-        stream, sizes = dd.gather_stream(seg, seg.numel(), dst=0)
-        gathered = sum(sizes)
+        line["ms_per_step"] = round(float(t.item()) / args.steps * 1e3, 4)
+        finished = copy.deepcopy(line)
+
+        def give_up():
+            if rank == 0:
+                finished["gather"] = {"error": "the exchange leg did not finish (a collective was never answered); "
+                                               f"the process leaves with code {EXIT_EXCHANGE_FAILED}"}
+                emit(finished)
+
+        # the exchange leg as the real run has it: under the watchdog.  DBDE_BENCH_DRY_FAIL=skip_gather makes the last
+        # rank walk past the gather, so that the others wait for a collective nobody answers (tests/test_bench_contract.py)
+        with Watchdog(float(os.environ.get("DBDE_BENCH_WATCHDOG_S", "300")), give_up):
+            if not (os.environ.get("DBDE_BENCH_DRY_FAIL") == "skip_gather" and rank == world - 1):
+                seg = torch.full((100 + 7 * rank,), rank, dtype=torch.uint8)
+                stream, sizes = dd.gather_stream(seg, seg.numel(), dst=0)
+                gathered = sum(sizes)
+            else:
+                time.sleep(3600)   # (the launcher ends this rank when rank 0 has left)
+        line["gathered_bytes"] = gathered
+    else:
+        line["ms_per_step"] = round(float(t.item()) / args.steps * 1e3, 4)
     if rank == 0:
-        emit({"metric": "frames/s + raw-pixel GB/s, 4096x3072 U8 encode+decode round-trip", "value": 0.0,
-                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-                          "data": "none (dry run: launch contract only, no GPU work, not a measurement)",
-                          "dry_run": True, "frames_of_rank0": [lo, hi], "gathered_bytes": gathered,
-                          "config": {"workload": "dry run"}})
+        emit(line)
 
 
 def main():
@@ -718,12 +738,18 @@ def main():
         if gather_mode and world > 1 and not args.only:
             c5 = CONFIGS[5]
 
+            # what the line holds BEFORE the leg starts: the watchdog fires on a timer thread while this thread may be in
+            # the middle of adding to `line`, so it prints this finished copy, never the live dictionary
+            finished = copy.deepcopy(line)
+
             def give_up():
                 if rank == 0:
-                    line["gather"] = {"error": "the exchange leg did not finish within 300 s (a collective was never answered)"}
-                    emit(line)
+                    finished["gather"] = {"error": f"the exchange leg did not finish within {watchdog_s:.0f} s (a collective was never answered); "
+                                                   f"the process leaves with code {EXIT_EXCHANGE_FAILED}"}
+                    emit(finished)
 
-            with Watchdog(300.0, give_up):
+            watchdog_s = float(os.environ.get("DBDE_BENCH_WATCHDOG_S", "300"))
+            with Watchdog(watchdog_s, give_up):
                 for mode in ([gather_mode, "nccl"] if gather_mode == "native" else [gather_mode]):
                     try:
                         cols, _ = b.stream(c5["W"], c5["H"], c5["frames"], args.batch, c5["content"], mode)
@@ -756,9 +782,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(mk, 4096, 3072)
         emit(line)
     if dist is not None:
-        if gather_failed:    # the communicator may be unusable: leave without the farewell collective
-            sys.stdout.flush()
-            os._exit(0)
+        if gather_failed:    # the communicator may be unusable: leave without the farewell collective -- and NOT with 0:
+            sys.stdout.flush()   # the line (printed above, with the error in it) comes from a run whose exchange failed
+            sys.stderr.flush()
+            os._exit(EXIT_EXCHANGE_FAILED)
         dist.barrier()
         dist.destroy_process_group()
 

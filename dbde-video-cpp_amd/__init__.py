@@ -49,6 +49,11 @@ C_ABI_SYMBOLS = [
     "dbde_hip_gather_unique_id", "dbde_hip_gather_create", "dbde_hip_gather_attach", "dbde_hip_gather_destroy",
     "dbde_hip_gather_error", "dbde_hip_gather_set_max_message", "dbde_hip_gather_begin", "dbde_hip_gather_post",
     "dbde_hip_gather_join", "dbde_hip_gather_sync", "dbde_hip_gather_rccl_version", "dbde_hip_gather_plan",
+    "dbde_hip_gather_set_window", "dbde_hip_gather_check",
+    "dbde_hip_scatter_create", "dbde_hip_scatter_attach", "dbde_hip_scatter_destroy", "dbde_hip_scatter_error",
+    "dbde_hip_scatter_set_max_message", "dbde_hip_scatter_set_capacity", "dbde_hip_scatter_begin", "dbde_hip_scatter_post",
+    "dbde_hip_scatter_join", "dbde_hip_scatter_sync", "dbde_hip_scatter_blocks", "dbde_hip_scatter_check",
+    "dbde_hip_scatter_plan",
 ]
 
 
@@ -71,6 +76,19 @@ class VideoHeader(C.Structure):
 
 class FrameResult(C.Structure):
     _fields_ = [("header", FrameHeader), ("consumed", C.c_uint64)]
+
+
+class ScatterBlock(C.Structure):
+    _fields_ = [("first_frame", C.c_uint64), ("n_frames", C.c_uint64), ("byte_start", C.c_uint64), ("byte_count", C.c_uint64)]
+
+
+class ScatterOp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("kind", C.c_int32), ("source_offset", C.c_uint64), ("dest_offset", C.c_uint64),
+                ("bytes", C.c_uint64)]
+
+
+SCATTER_SEND_BYTES, SCATTER_RECV_BYTES, SCATTER_SEND_OFFSETS, SCATTER_RECV_OFFSETS, SCATTER_OWN = 1, 2, 3, 4, 5
+SCATTER_LOOPBACK = 1
 
 
 class GatherOp(C.Structure):
@@ -201,6 +219,36 @@ def lib():
     L.dbde_hip_gather_rccl_version.argtypes = []
     L.dbde_hip_gather_plan.restype = i
     L.dbde_hip_gather_plan.argtypes = [i, i, i, C.POINTER(u64), u64, C.POINTER(GatherOp), i, C.POINTER(u64)]
+    L.dbde_hip_gather_set_window.restype = i
+    L.dbde_hip_gather_set_window.argtypes = [vp, u64]
+    L.dbde_hip_gather_check.restype = i
+    L.dbde_hip_gather_check.argtypes = [i, i, C.POINTER(u64), C.POINTER(u64)]
+    L.dbde_hip_scatter_create.restype = i
+    L.dbde_hip_scatter_create.argtypes = [vp, vp, i, i, i, C.POINTER(vp)]
+    L.dbde_hip_scatter_attach.restype = i
+    L.dbde_hip_scatter_attach.argtypes = [vp, vp, i, i, i, C.POINTER(vp)]
+    L.dbde_hip_scatter_destroy.restype = None
+    L.dbde_hip_scatter_destroy.argtypes = [vp]
+    L.dbde_hip_scatter_error.restype = C.c_char_p
+    L.dbde_hip_scatter_error.argtypes = [vp]
+    L.dbde_hip_scatter_set_max_message.restype = i
+    L.dbde_hip_scatter_set_max_message.argtypes = [vp, u64]
+    L.dbde_hip_scatter_set_capacity.restype = i
+    L.dbde_hip_scatter_set_capacity.argtypes = [vp, u64, u64]
+    L.dbde_hip_scatter_begin.restype = i
+    L.dbde_hip_scatter_begin.argtypes = [vp, i, vp, u64, vp, vp]
+    L.dbde_hip_scatter_post.restype = i
+    L.dbde_hip_scatter_post.argtypes = [vp, i, vp, vp, C.POINTER(ScatterBlock), C.POINTER(ScatterBlock), C.c_uint32]
+    L.dbde_hip_scatter_join.restype = i
+    L.dbde_hip_scatter_join.argtypes = [vp, i]
+    L.dbde_hip_scatter_sync.restype = i
+    L.dbde_hip_scatter_sync.argtypes = [vp, i]
+    L.dbde_hip_scatter_blocks.restype = i
+    L.dbde_hip_scatter_blocks.argtypes = [i, u64, C.POINTER(u64), u64, C.POINTER(ScatterBlock)]
+    L.dbde_hip_scatter_check.restype = i
+    L.dbde_hip_scatter_check.argtypes = [i, C.POINTER(ScatterBlock), C.POINTER(u64)]
+    L.dbde_hip_scatter_plan.restype = i
+    L.dbde_hip_scatter_plan.argtypes = [i, i, i, C.POINTER(ScatterBlock), u64, C.POINTER(ScatterOp), i]
     _lib = L
     return L
 
@@ -256,6 +304,49 @@ def decode_plan(W, H, n_frames, image_address=0, n_cu=256):
     if rc != OK:
         raise ValueError(f"dbde_hip_decode_plan({W}, {H}, {n_frames}) -> {rc}")
     return pl.as_dict()
+
+
+def gather_check(nranks, root, sizes, caps):
+    """dbde_hip_gather_check: (verdict, total) every rank reaches from the exchanged {count, capacity} pairs."""
+    pairs = (C.c_uint64 * (2 * nranks))(*[int(x) for r in range(nranks) for x in (sizes[r], caps[r])])
+    total = C.c_uint64(0)
+    rc = lib().dbde_hip_gather_check(nranks, root, pairs, C.byref(total))
+    return rc, int(total.value)
+
+
+def scatter_blocks(nranks, frame_offsets, stream_bytes):
+    """dbde_hip_scatter_blocks: [(first_frame, n_frames, byte_start, byte_count)] per rank from a host-side frame index."""
+    n = len(frame_offsets)
+    arr = (C.c_uint64 * max(n, 1))(*[int(x) for x in frame_offsets])
+    table = (ScatterBlock * nranks)()
+    rc = lib().dbde_hip_scatter_blocks(nranks, n, arr, int(stream_bytes), table)
+    if rc != OK:
+        raise ValueError(f"dbde_hip_scatter_blocks -> {rc}")
+    return [(int(b.first_frame), int(b.n_frames), int(b.byte_start), int(b.byte_count)) for b in table]
+
+
+def _scatter_table(blocks):
+    table = (ScatterBlock * len(blocks))()
+    for k, b in enumerate(blocks):
+        table[k].first_frame, table[k].n_frames, table[k].byte_start, table[k].byte_count = [int(x) for x in b]
+    return table
+
+
+def scatter_check(blocks, caps):
+    """dbde_hip_scatter_check: OK or ERR_CAPACITY; caps = [(segment_bytes, max_frames)] per rank."""
+    flat = (C.c_uint64 * (2 * len(caps)))(*[int(x) for c in caps for x in c])
+    return lib().dbde_hip_scatter_check(len(blocks), _scatter_table(blocks), flat)
+
+
+def scatter_plan(nranks, rank, root, blocks, max_piece=0):
+    """dbde_hip_scatter_plan: the ordered transfers of `rank` -> [(peer, kind, source_offset, dest_offset, bytes)]."""
+    table = _scatter_table(blocks)
+    n = lib().dbde_hip_scatter_plan(nranks, rank, root, table, max_piece, None, 0)
+    if n < 0:
+        raise ValueError(f"dbde_hip_scatter_plan({nranks}, {rank}, {root}) -> {n}")
+    ops = (ScatterOp * max(n, 1))()
+    lib().dbde_hip_scatter_plan(nranks, rank, root, table, max_piece, ops, n)
+    return [(o.peer, o.kind, int(o.source_offset), int(o.dest_offset), int(o.bytes)) for o in ops[:n]]
 
 
 def gather_unique_id():
@@ -527,6 +618,10 @@ class Gather:
         if rc != OK:
             raise DbdeError(f"dbde_hip_gather_{what} failed ({rc}): {self.codec.L.dbde_hip_gather_error(self.h).decode()}")
 
+    def set_window(self, window_bytes):
+        """Root: the bytes its window holds; travels with every size exchange so that an overflow is ONE verdict on all ranks."""
+        self._check(self.codec.L.dbde_hip_gather_set_window(self.h, int(window_bytes)), "set_window")
+
     def begin(self, slot, last_offset, last_bytes):
         """last_offset / last_bytes: 1-element int64 device tensors (views of the encoder's outputs) or None."""
         self._check(self.codec.L.dbde_hip_gather_begin(self.h, slot, last_offset.data_ptr() if last_offset is not None else None,
@@ -551,6 +646,64 @@ class Gather:
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
             self.codec.L.dbde_hip_gather_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scatter:
+    """dbde_hip_scatter_*: this rank's end of the scatter of a .dbde body to the ranks' frame blocks (RCCL): the decode-side
+    mirror of Gather.  `unique_id` as for Gather, or `comm` = an ncclComm_t."""
+
+    def __init__(self, codec, unique_id, nranks, rank, root=0, comm=None, max_message_bytes=None):
+        self.codec, self.nranks, self.rank, self.root = codec, nranks, rank, root
+        self.h = C.c_void_p()
+        if comm is not None:
+            rc = codec.L.dbde_hip_scatter_attach(codec.h, C.c_void_p(comm), nranks, rank, root, C.byref(self.h))
+        else:
+            uid = np.ascontiguousarray(np.asarray(unique_id, np.uint8))
+            assert uid.size == GATHER_ID_BYTES
+            rc = codec.L.dbde_hip_scatter_create(codec.h, uid.ctypes.data, nranks, rank, root, C.byref(self.h))
+        if rc != OK or not self.h.value:
+            raise DbdeError(f"dbde_hip_scatter_create failed ({rc})")
+        if max_message_bytes:
+            self._check(codec.L.dbde_hip_scatter_set_max_message(self.h, int(max_message_bytes)), "set_max_message")
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise DbdeError(f"dbde_hip_scatter_{what} failed ({rc}): {self.codec.L.dbde_hip_scatter_error(self.h).decode()}")
+
+    def set_capacity(self, segment_bytes, max_frames):
+        self._check(self.codec.L.dbde_hip_scatter_set_capacity(self.h, int(segment_bytes), int(max_frames)), "set_capacity")
+
+    def begin(self, slot, stream=None, stream_offset=0, stream_bytes=0, offsets=None, count=None):
+        """Root: the stream (uint8 device tensor), its extent, the scanner's offsets (int64) and count (int32, 1 element)."""
+        self._check(self.codec.L.dbde_hip_scatter_begin(
+            self.h, slot, stream.data_ptr() + stream_offset if stream is not None else None, int(stream_bytes),
+            offsets.data_ptr() if offsets is not None else None, count.data_ptr() if count is not None else None), "begin")
+
+    def post(self, slot, segment, offsets_out, loopback=False):
+        """-> (mine, table): (first_frame, n_frames, byte_start, byte_count) of this rank and of every rank."""
+        mine, table = ScatterBlock(), (ScatterBlock * self.nranks)()
+        self._check(self.codec.L.dbde_hip_scatter_post(self.h, slot, segment.data_ptr() if segment is not None else None,
+                                                       offsets_out.data_ptr(), C.byref(mine), table,
+                                                       SCATTER_LOOPBACK if loopback else 0), "post")
+        t = lambda b: (int(b.first_frame), int(b.n_frames), int(b.byte_start), int(b.byte_count))
+        return t(mine), [t(b) for b in table]
+
+    def join(self, slot):
+        self._check(self.codec.L.dbde_hip_scatter_join(self.h, slot), "join")
+
+    def sync(self, slot):
+        self._check(self.codec.L.dbde_hip_scatter_sync(self.h, slot), "sync")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.codec.L.dbde_hip_scatter_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -17,9 +17,7 @@
 //     window: displacement 0).
 // librccl is opened at run time (dlopen "librccl.so.1": in a PyTorch process that is the copy torch has loaded, so the
 // process holds ONE RCCL), which keeps single-GPU users of libdbde_hip.so free of the dependency.
-#include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -29,55 +27,17 @@
 #include <vector>
 
 #include "../../include/dbde_hip.h"
+#include "dbde_rccl.h"
 
 namespace {
 
-struct Rccl {
-    void *handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    decltype(&ncclGetVersion) GetVersion = nullptr;
-    std::string err;
-};
+using dbde_rccl::Rccl;
+using dbde_rccl::rccl;
 
-Rccl *rccl() {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) {
-            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (r.handle) break;
-        }
-        if (!r.handle) { r.err = std::string("librccl not found: ") + dlerror(); return; }
-#define DBDE_RCCL_SYM(field, name)                                             \
-    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, #name));     \
-    if (!r.field) { r.err = "librccl lacks " #name; r.handle = nullptr; return; }
-        DBDE_RCCL_SYM(GetUniqueId, ncclGetUniqueId)
-        DBDE_RCCL_SYM(CommInitRank, ncclCommInitRank)
-        DBDE_RCCL_SYM(CommDestroy, ncclCommDestroy)
-        DBDE_RCCL_SYM(AllGather, ncclAllGather)
-        DBDE_RCCL_SYM(Send, ncclSend)
-        DBDE_RCCL_SYM(Recv, ncclRecv)
-        DBDE_RCCL_SYM(GroupStart, ncclGroupStart)
-        DBDE_RCCL_SYM(GroupEnd, ncclGroupEnd)
-        DBDE_RCCL_SYM(GetErrorString, ncclGetErrorString)
-        DBDE_RCCL_SYM(GetVersion, ncclGetVersion)
-#undef DBDE_RCCL_SYM
-    });
-    return r.handle ? &r : nullptr;
-}
-
-// the batch's byte count: offset of its last frame + that frame's length (either word may be absent)
-__global__ void gather_count_kernel(const uint64_t *a, const uint64_t *b, uint64_t *out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (a ? *a : 0ull) + (b ? *b : 0ull);
+// the batch's byte count: offset of its last frame + that frame's length (either word may be absent); beside it the
+// capacity of the root's window as this rank knows it (the root's own word is the one that counts)
+__global__ void gather_count_kernel(const uint64_t *a, const uint64_t *b, uint64_t cap, uint64_t *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = (a ? *a : 0ull) + (b ? *b : 0ull); out[1] = cap; }
 }
 
 constexpr int kSlots = 2;
@@ -91,8 +51,9 @@ struct dbde_hip_gather {
     bool own_comm = false;
     hipStream_t ctx_stream = nullptr, comm_stream = nullptr;
     uint64_t max_piece = 1ull << 30;
+    uint64_t window_cap = ~0ull;      // root: bytes its window holds (dbde_hip_gather_set_window); travels with every size exchange
     struct Slot {
-        uint64_t *d_mine = nullptr, *d_sizes = nullptr;   // device: this rank's count, every rank's count
+        uint64_t *d_mine = nullptr, *d_sizes = nullptr;   // device: this rank's {count, window capacity}, every rank's pair
         uint64_t *h_sizes = nullptr;                      // pinned host copy of d_sizes
         hipEvent_t ev_ready = nullptr, ev_sizes = nullptr, ev_done = nullptr;
         bool begun = false;
@@ -128,10 +89,10 @@ int setup(dbde_hip_gather *g) {
     G_HIP(g, hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking));
     for (auto &s : g->slot) {
         void *p = nullptr;
-        G_HIP(g, hipMalloc(&p, 8 * (size_t)(g->nranks + 1)));
+        G_HIP(g, hipMalloc(&p, 16 * (size_t)(g->nranks + 1)));
         s.d_mine = reinterpret_cast<uint64_t *>(p);
-        s.d_sizes = s.d_mine + 1;
-        G_HIP(g, hipHostMalloc(&p, 8 * (size_t)g->nranks, hipHostMallocDefault));
+        s.d_sizes = s.d_mine + 2;
+        G_HIP(g, hipHostMalloc(&p, 16 * (size_t)g->nranks, hipHostMallocDefault));
         s.h_sizes = reinterpret_cast<uint64_t *>(p);
         G_HIP(g, hipEventCreateWithFlags(&s.ev_ready, hipEventDisableTiming));
         G_HIP(g, hipEventCreateWithFlags(&s.ev_sizes, hipEventDisableTiming));
@@ -175,6 +136,20 @@ int dbde_hip_gather_plan(int nranks, int rank, int root, const uint64_t *sizes, 
     }
     if (total_out) *total_out = total;
     return n;
+}
+
+// The verdict every rank reaches from the exchanged {count, capacity} pairs -- the same on all of them, so that either
+// everybody posts its transfers or nobody does (a root that found its window too small while its peers had already
+// posted their sends left them waiting for ever).
+int dbde_hip_gather_check(int nranks, int root, const uint64_t *pairs, uint64_t *total_out) {
+    if (nranks < 1 || root < 0 || root >= nranks || !pairs) return DBDE_HIP_ERR_ARG;
+    uint64_t total = 0;
+    for (int r = 0; r < nranks; r++) {
+        if (pairs[2 * r] > ~0ull - total) return DBDE_HIP_ERR_CAPACITY;
+        total += pairs[2 * r];
+    }
+    if (total_out) *total_out = total;
+    return total > pairs[2 * root + 1] ? DBDE_HIP_ERR_CAPACITY : DBDE_HIP_OK;
 }
 
 int dbde_hip_gather_unique_id(uint8_t id[DBDE_HIP_GATHER_ID_BYTES]) {
@@ -249,6 +224,12 @@ int dbde_hip_gather_set_max_message(dbde_hip_gather *g, uint64_t bytes) {
     return DBDE_HIP_OK;
 }
 
+int dbde_hip_gather_set_window(dbde_hip_gather *g, uint64_t window_bytes) {
+    if (!g) return DBDE_HIP_ERR_ARG;
+    g->window_cap = window_bytes;
+    return DBDE_HIP_OK;
+}
+
 int dbde_hip_gather_begin(dbde_hip_gather *g, int slot, const uint64_t *d_last_offset, const uint64_t *d_last_bytes) {
     if (!g || slot < 0 || slot >= kSlots) return DBDE_HIP_ERR_ARG;
     auto &s = g->slot[slot];
@@ -256,10 +237,11 @@ int dbde_hip_gather_begin(dbde_hip_gather *g, int slot, const uint64_t *d_last_o
     // behind everything the codec's stream holds so far (the encode that produces the count and the bytes)
     G_HIP(g, hipEventRecord(s.ev_ready, g->ctx_stream));
     G_HIP(g, hipStreamWaitEvent(g->comm_stream, s.ev_ready, 0));
-    hipLaunchKernelGGL(gather_count_kernel, dim3(1), dim3(64), 0, g->comm_stream, d_last_offset, d_last_bytes, s.d_mine);
+    hipLaunchKernelGGL(gather_count_kernel, dim3(1), dim3(64), 0, g->comm_stream, d_last_offset, d_last_bytes,
+                       g->rank == g->root ? g->window_cap : 0ull, s.d_mine);
     G_HIP(g, hipGetLastError());
-    G_NCCL(g, rccl()->AllGather(s.d_mine, s.d_sizes, 1, ncclUint64, g->comm, g->comm_stream));
-    G_HIP(g, hipMemcpyAsync(s.h_sizes, s.d_sizes, 8 * (size_t)g->nranks, hipMemcpyDeviceToHost, g->comm_stream));
+    G_NCCL(g, rccl()->AllGather(s.d_mine, s.d_sizes, 2, ncclUint64, g->comm, g->comm_stream));
+    G_HIP(g, hipMemcpyAsync(s.h_sizes, s.d_sizes, 16 * (size_t)g->nranks, hipMemcpyDeviceToHost, g->comm_stream));
     G_HIP(g, hipEventRecord(s.ev_sizes, g->comm_stream));
     s.begun = true;
     return DBDE_HIP_OK;
@@ -274,14 +256,21 @@ int dbde_hip_gather_post(dbde_hip_gather *g, int slot, const uint8_t *d_segment,
     G_HIP(g, hipSetDevice(g->device));
     G_HIP(g, hipEventSynchronize(s.ev_sizes));   // the HOST waits for the counts; the codec's stream is not involved
     s.begun = false;
-    if (sizes_out) memcpy(sizes_out, s.h_sizes, 8 * (size_t)g->nranks);
+    std::vector<uint64_t> sizes((size_t)g->nranks);
+    for (int r = 0; r < g->nranks; r++) sizes[(size_t)r] = s.h_sizes[2 * r];
+    if (sizes_out) memcpy(sizes_out, sizes.data(), 8 * (size_t)g->nranks);
+    // The data-dependent verdict is the same on every rank (the root's capacity travelled with the counts): all post or none
     uint64_t total = 0;
-    const int n_ops = dbde_hip_gather_plan(g->nranks, g->rank, g->root, s.h_sizes, g->max_piece, nullptr, 0, &total);
+    if (dbde_hip_gather_check(g->nranks, g->root, s.h_sizes, &total) != DBDE_HIP_OK)
+        return gfail(g, DBDE_HIP_ERR_CAPACITY, "gather_post: %llu bytes do not fit the root window (%llu): nothing posted on any rank",
+                     (unsigned long long)total, (unsigned long long)s.h_sizes[2 * g->root + 1]);
+    if (g->rank == g->root && total > window_bytes)   // (a caller's error, not the data's: the window is smaller than what was declared)
+        return gfail(g, DBDE_HIP_ERR_ARG, "gather_post: window_bytes %zu below the declared capacity (dbde_hip_gather_set_window) and the %llu bytes on their way",
+                     window_bytes, (unsigned long long)total);
+    const int n_ops = dbde_hip_gather_plan(g->nranks, g->rank, g->root, sizes.data(), g->max_piece, nullptr, 0, &total);
     if (n_ops < 0) return gfail(g, DBDE_HIP_ERR_ARG, "gather_post: bad plan");
-    if (g->rank == g->root && total > window_bytes)
-        return gfail(g, DBDE_HIP_ERR_CAPACITY, "gather_post: %llu bytes do not fit the root window (%zu)", (unsigned long long)total, window_bytes);
     std::vector<dbde_hip_gather_op> ops((size_t)n_ops);
-    (void)dbde_hip_gather_plan(g->nranks, g->rank, g->root, s.h_sizes, g->max_piece, ops.data(), n_ops, nullptr);
+    (void)dbde_hip_gather_plan(g->nranks, g->rank, g->root, sizes.data(), g->max_piece, ops.data(), n_ops, nullptr);
     Rccl *R = rccl();
     const bool loopback = (flags & DBDE_HIP_GATHER_LOOPBACK) != 0 && g->rank == g->root;
     if (loopback)

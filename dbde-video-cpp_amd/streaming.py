@@ -24,6 +24,28 @@ import torch
 from . import distributed as dd
 
 
+def drive_rounds(ops, rounds, nb, count, gather, native):
+    """The control flow of RoundTripStream.run, separated from the GPU so that it can be tested without one
+    (tests/test_streaming_order.py): `ops` supplies op_encode / op_begin / op_decode / op_produce / op_post.
+    Every rank walks the same `rounds` iterations, so that the collective calls (size exchange of round k, then the
+    transfers of round k - 1) are issued in the same order everywhere; a rank whose block has fewer batches (`nb`) takes
+    part in the remaining rounds with nothing to send (count(k) == 0: no encode, but the same begin and post)."""
+    for k in range(rounds):
+        slot, n = k % 2, count(k)
+        if n:
+            ops.op_encode(k, slot, n)        # (waits, on the codec's stream, for the transfer that last read this slot)
+        if native:
+            ops.op_begin(slot, n)
+        if n and ops.decode:
+            ops.op_decode(slot, n)
+        if k + 2 < nb:
+            ops.op_produce(k + 2, slot)
+        if gather and k >= 1:                # one round behind: the host wait for the counts ends early
+            ops.op_post((k - 1) % 2, count(k - 1))
+    if gather and rounds:
+        ops.op_post((rounds - 1) % 2, count(rounds - 1))
+
+
 class RoundTripStream:
     """Encode+decode `n_frames` frames [first_frame, first_frame + n_frames) in batches of `batch`.
 
@@ -70,6 +92,8 @@ class RoundTripStream:
             self.window = [torch.empty(lead + world * cap + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
             if not loopback:
                 self.out = [(self.window[k], lead, cap) for k in range(2)]
+            if native is not None:
+                native.set_window(world * cap)     # travels with every size exchange: an overflow is one verdict on all ranks
 
     def _produce(self, slot, first, n):
         if self.source is None:
@@ -116,6 +140,47 @@ class RoundTripStream:
         sizes = self.native.post(slot, buf, lead, win, lead, world * cap, loopback=self.loopback)
         return sizes[self.native.rank], sum(sizes)
 
+    # ---- the operations of one round (drive_rounds calls them in the order that keeps the collectives in step) ----
+    def op_join(self, slot):
+        if self.gather == "native":
+            self.native.join(slot)                           # the transfer that read this slot is done
+        else:
+            self.s_codec.wait_event(self.ev_gath[slot])
+
+    def op_encode(self, k, slot, n):
+        first_frame = self._geo[0]
+        buf, lead, cap = self.out[slot]
+        with torch.cuda.stream(self.s_codec):
+            if self.source is not None:
+                self.s_codec.wait_event(self.ev_src[slot])
+            self.op_join(slot)
+            self.codec.encode_frames(self.inp[slot], self.W, self.H, n, buf, lead, cap, first_index=first_frame + k * self.batch,
+                                     offsets=self.offs[slot], nbytes=self.sizes[slot])
+            self.ev_enc[slot].record(self.s_codec)
+            if self.tap is not None:
+                self.tap(k, slot, n)
+
+    def op_begin(self, slot, n):
+        with torch.cuda.stream(self.s_codec):
+            self._native_begin(slot, n)      # size exchange enqueued behind the encode; returns at once
+
+    def op_decode(self, slot, n):
+        buf, lead, cap = self.out[slot]
+        with torch.cuda.stream(self.s_codec):
+            self.codec.decode_frames(buf, lead, cap, self.offs[slot], self.W, self.H, n, images=self.img, results=self.res)
+            if self.check:
+                self.mismatches += int((self.img[:n] != self.inp[slot][:n]).any().item())
+
+    def op_produce(self, k, slot):
+        first_frame, _, _, _, count = self._geo
+        self._produce(slot, first_frame + k * self.batch, count(k))
+
+    def op_post(self, slot, n):
+        _, world, rank, _, _ = self._geo
+        a, b = self._native_post(slot, world) if self.gather == "native" else self._post_gather(slot, n, world, rank)
+        self._acc[0] += a
+        self._acc[1] += b
+
     def run(self, first_frame, n_frames, world=1, rank=0, rounds=None):
         """Returns a dict: frames, seconds (host wall, everything drained), packed bytes of this rank,
         gathered bytes (root's view of every rank) when gathering.  `rounds`: gather rounds every rank takes
@@ -129,42 +194,12 @@ class RoundTripStream:
             ev.record(self.s_codec)
         for k in range(min(2, nb)):
             self._produce(k, first_frame + k * B, count(k))
-        packed = gathered = 0
+        self._acc = [0, 0]
+        self._geo = (first_frame, world, rank, nb, count)
         torch.cuda.synchronize(self.dev)      # the first two batches are resident when the clock starts
         t0 = time.perf_counter()
-        # Every rank walks the same `rounds` iterations, so that the collective calls (size exchange of round k, then
-        # the transfers of round k-1) are issued in the same order everywhere; a rank whose block has fewer batches
-        # takes part in the remaining rounds with nothing to send.
-        for k in range(rounds):
-            slot, n = k % 2, count(k)
-            buf, lead, cap = self.out[slot]
-            with torch.cuda.stream(self.s_codec):
-                if n:
-                    if self.source is not None:
-                        self.s_codec.wait_event(self.ev_src[slot])
-                    if native:
-                        self.native.join(slot)                           # the transfer that read this slot is done
-                    else:
-                        self.s_codec.wait_event(self.ev_gath[slot])
-                    codec.encode_frames(self.inp[slot], W, H, n, buf, lead, cap, first_index=first_frame + k * B,
-                                        offsets=self.offs[slot], nbytes=self.sizes[slot])
-                    self.ev_enc[slot].record(self.s_codec)
-                    if self.tap is not None:
-                        self.tap(k, slot, n)
-                if native:
-                    self._native_begin(slot, n)      # size exchange enqueued behind the encode; returns at once
-                if n and self.decode:
-                    codec.decode_frames(buf, lead, cap, self.offs[slot], W, H, n, images=self.img, results=self.res)
-                    if self.check:
-                        self.mismatches += int((self.img[:n] != self.inp[slot][:n]).any().item())
-            if k + 2 < nb:
-                self._produce(slot, first_frame + (k + 2) * B, count(k + 2))
-            if self.gather and k >= 1:       # one round behind: the host wait for the counts ends early
-                a, b = self._native_post((k - 1) % 2, world) if native else self._post_gather((k - 1) % 2, count(k - 1), world, rank)
-                packed, gathered = packed + a, gathered + b
-        if self.gather and rounds:
-            a, b = self._native_post((rounds - 1) % 2, world) if native else self._post_gather((rounds - 1) % 2, count(rounds - 1), world, rank)
-            packed, gathered = packed + a, gathered + b
+        drive_rounds(self, rounds, nb, count, bool(self.gather), native)
+        packed, gathered = self._acc
         if native:
             for slot in range(2):
                 self.native.sync(slot)

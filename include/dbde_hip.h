@@ -271,6 +271,14 @@ void dbde_hip_gather_destroy(dbde_hip_gather *g);
 const char *dbde_hip_gather_error(const dbde_hip_gather *g);
 /* Messages are cut into pieces of at most this many bytes (default 1 GiB), all posted in one group. */
 int dbde_hip_gather_set_max_message(dbde_hip_gather *g, uint64_t bytes);
+/* Root: the bytes its window holds (default: no limit declared).  The value travels with every size exchange, so that
+ * "the batch does not fit" is a verdict EVERY rank reaches from the same numbers (dbde_hip_gather_post then returns
+ * DBDE_HIP_ERR_CAPACITY on all ranks and nothing has been posted anywhere; a root that found out alone used to leave
+ * its peers' sends unmatched).  Call it once, before the first dbde_hip_gather_begin. */
+int dbde_hip_gather_set_window(dbde_hip_gather *g, uint64_t window_bytes);
+/* The verdict itself, pure arithmetic: pairs[2 r] = rank r's count, pairs[2 r + 1] = the window capacity rank r declared
+ * (only the root's counts).  DBDE_HIP_OK or DBDE_HIP_ERR_CAPACITY; *total_out = sum of the counts. */
+int dbde_hip_gather_check(int nranks, int root, const uint64_t *pairs, uint64_t *total_out);
 /* Enqueues the size exchange of `slot` (0 or 1) behind everything on the context's stream: this rank's byte count
  * is the sum of the two DEVICE words (either may be NULL = 0; the encoder's offset and length of the batch's last
  * frame).  Does not wait for anything. */
@@ -280,8 +288,9 @@ int dbde_hip_gather_begin(dbde_hip_gather *g, int slot, const uint64_t *d_last_o
  * gather's own stream: a non-root rank sends d_segment[0, its count) to the root; the root receives rank r's bytes
  * at d_window + sum(counts of ranks < r).  The root's own bytes are not moved when d_segment already is
  * d_window + its displacement (root 0 encoding straight into its window), else copied once device-to-device.
- * window_bytes (root) must hold the sum of all counts -- size it as nranks x the per-rank capacity: a root that
- * returns DBDE_HIP_ERR_CAPACITY has posted nothing and its peers' sends stay unmatched.  sizes_out: optional host
+ * window_bytes (root) must hold the sum of all counts -- size it as nranks x the per-rank capacity and declare it
+ * with dbde_hip_gather_set_window: DBDE_HIP_ERR_CAPACITY is then returned by EVERY rank, with nothing posted.  (A root
+ * whose window_bytes is below what it declared gets DBDE_HIP_ERR_ARG: a caller's error, not the data's.)  sizes_out: optional host
  * array of nranks counts.  flags: DBDE_HIP_GATHER_LOOPBACK (tests and one-GPU rehearsals) sends the root's own
  * segment to itself through ncclSend / ncclRecv instead. */
 #define DBDE_HIP_GATHER_LOOPBACK 1u
@@ -306,6 +315,64 @@ typedef struct {
 } dbde_hip_gather_op;
 int dbde_hip_gather_plan(int nranks, int rank, int root, const uint64_t *sizes, uint64_t max_piece,
                          dbde_hip_gather_op *ops, int max_ops, uint64_t *total_out);
+
+/* ---- multi-GPU: scatter of a .dbde body to the ranks' frame blocks (the decode-side mirror of the gather) ------ */
+/* A root holds a stream of frames following each other (README.md:12-23) and the frame starts the device scanner found
+ * (dbde_hip_index_stream_async; the serial reader this replaces is dbde_util.cpp:408-421).  Rank r of G gets the bytes of
+ * frames [r n / G, (r + 1) n / G) -- the gather's blocks -- and the offsets of those frames relative to its segment, and
+ * decodes them with dbde_hip_decode_frames.  The block table is worked out on the device from the scanner's outputs and
+ * broadcast (ncclBroadcast), every rank's buffer capacities are all-gathered beside it, the bytes and the offsets travel
+ * as grouped ncclSend / ncclRecv; the root's own block is not moved.  Two slots, as for the gather.  Per batch:
+ *   root:   dbde_hip_index_stream_async(ctx, d_stream, bytes, W, H, max, d_offsets, d_count)
+ *   all:    dbde_hip_scatter_begin(s, slot, d_stream, bytes, d_offsets, d_count)      (non-root ranks pass NULL / 0)
+ *   all:    dbde_hip_scatter_post(s, slot, d_segment, d_my_offsets, &mine, NULL, 0)   host waits for the table only
+ *   all:    dbde_hip_scatter_join(s, slot)
+ *   all:    dbde_hip_decode_frames(ctx, root ? d_stream + mine.byte_start : d_segment, mine.byte_count, d_my_offsets, W, H,
+ *                                  (int)mine.n_frames, d_images, d_results)
+ * Collective: every rank makes the same begin / post calls in the same order.  UNMEASURED on hardware beyond one rank. */
+typedef struct dbde_hip_scatter dbde_hip_scatter;
+typedef struct {
+    uint64_t first_frame, n_frames;   /* the rank's frame block: global frame numbers [first_frame, first_frame + n_frames) */
+    uint64_t byte_start, byte_count;  /* its bytes in the root's stream */
+} dbde_hip_scatter_block;
+int dbde_hip_scatter_create(dbde_hip_ctx *ctx, const uint8_t id[DBDE_HIP_GATHER_ID_BYTES], int nranks, int rank,
+                            int root, dbde_hip_scatter **out);      /* collective (ncclCommInitRank); id: dbde_hip_gather_unique_id */
+int dbde_hip_scatter_attach(dbde_hip_ctx *ctx, void *nccl_comm, int nranks, int rank, int root, dbde_hip_scatter **out);
+void dbde_hip_scatter_destroy(dbde_hip_scatter *s);
+const char *dbde_hip_scatter_error(const dbde_hip_scatter *s);
+int dbde_hip_scatter_set_max_message(dbde_hip_scatter *s, uint64_t bytes);
+/* What this rank's receive buffers hold: segment bytes and frame offsets.  Travels with every table exchange, so that "a
+ * block does not fit" is DBDE_HIP_ERR_CAPACITY on EVERY rank with nothing posted (the root needs none: it decodes in place). */
+int dbde_hip_scatter_set_capacity(dbde_hip_scatter *s, uint64_t segment_bytes, uint64_t max_frames);
+/* Enqueues the table exchange of `slot` behind everything on the context's stream (the scanner).  Root: the stream, its
+ * readable extent, the scanner's offsets and its count word (all device).  Other ranks: NULL, 0, NULL, NULL. */
+int dbde_hip_scatter_begin(dbde_hip_scatter *s, int slot, const uint8_t *d_stream, uint64_t stream_bytes,
+                           const uint64_t *d_frame_offsets, const uint32_t *d_n_frames);
+/* Blocks the HOST until the table has arrived, then posts the transfers on the scatter's own stream.  d_segment: where a
+ * non-root rank's bytes land (root: unused unless DBDE_HIP_SCATTER_LOOPBACK, which sends the root's own block to itself
+ * through ncclSend / ncclRecv -- tests and one-GPU rehearsals); d_offsets_out: the block's frame offsets relative to its
+ * first byte (every rank).  mine_out / table_out (nranks entries): optional host copies of the table. */
+#define DBDE_HIP_SCATTER_LOOPBACK 1u
+int dbde_hip_scatter_post(dbde_hip_scatter *s, int slot, uint8_t *d_segment, uint64_t *d_offsets_out,
+                          dbde_hip_scatter_block *mine_out, dbde_hip_scatter_block *table_out, uint32_t flags);
+int dbde_hip_scatter_join(dbde_hip_scatter *s, int slot);   /* the context's stream waits for the slot's transfers */
+int dbde_hip_scatter_sync(dbde_hip_scatter *s, int slot);   /* the host does */
+/* The host logic both ends must agree on, pure arithmetic (no GPU): the block table from a host-side frame index, the
+ * capacity verdict (caps[2 r] = rank r's segment bytes, caps[2 r + 1] = its frame capacity), and the ordered transfers
+ * of `rank` (returns their number, filling at most max_ops). */
+enum { DBDE_HIP_SCATTER_SEND_BYTES = 1, DBDE_HIP_SCATTER_RECV_BYTES = 2, DBDE_HIP_SCATTER_SEND_OFFSETS = 3,
+       DBDE_HIP_SCATTER_RECV_OFFSETS = 4, DBDE_HIP_SCATTER_OWN = 5 };
+typedef struct {
+    int32_t peer, kind;
+    uint64_t source_offset;    /* bytes: offset in the root's stream; offsets: byte offset in the root's offset array */
+    uint64_t dest_offset;      /* byte offset in the receiver's segment / offsets buffer */
+    uint64_t bytes;
+} dbde_hip_scatter_op;
+int dbde_hip_scatter_blocks(int nranks, uint64_t n_frames, const uint64_t *frame_offsets, uint64_t stream_bytes,
+                            dbde_hip_scatter_block *table);
+int dbde_hip_scatter_check(int nranks, const dbde_hip_scatter_block *table, const uint64_t *caps);
+int dbde_hip_scatter_plan(int nranks, int rank, int root, const dbde_hip_scatter_block *table, uint64_t max_piece,
+                          dbde_hip_scatter_op *ops, int max_ops);
 
 /* ---- launch plans: which kernels a batch call runs (pure host arithmetic: no context, no device) ------------
  * The batch calls choose among several kernel forms by shape, batch size and buffer alignment;

@@ -62,8 +62,18 @@ int main() {
         if (a[i] != 0xEE || b[i] != 0xEE) { fprintf(stderr, "byte %zu behind the stream was touched\n", i); return 6; }
     // an unposted slot refuses a post; a window that is too small is refused before anything is posted
     if (dbde_hip_gather_post(g, 0, win_a, win_a, cap, sizes, 0) != DBDE_HIP_ERR_ARG) return 7;
+    // (the DECLARED capacity travels with the counts: "does not fit" is then one verdict on every rank, nothing posted;
+    // a window_bytes below what was declared is the caller's error)
+    OK(dbde_hip_gather_set_window(g, 16));
     OK(dbde_hip_gather_begin(g, 0, offs + (n - 1), bytes + (n - 1)));
     if (dbde_hip_gather_post(g, 0, win_a, win_a, 16, sizes, 0) != DBDE_HIP_ERR_CAPACITY) return 8;
+    OK(dbde_hip_gather_set_window(g, cap));
+    OK(dbde_hip_gather_begin(g, 0, offs + (n - 1), bytes + (n - 1)));
+    if (dbde_hip_gather_post(g, 0, win_a, win_a, 16, sizes, 0) != DBDE_HIP_ERR_ARG) return 9;
+    OK(dbde_hip_gather_begin(g, 0, offs + (n - 1), bytes + (n - 1)));
+    OK(dbde_hip_gather_post(g, 0, win_a, win_a, cap, sizes, 0));
+    OK(dbde_hip_gather_sync(g, 0));
+    if (sizes[0] != total) return 10;
     dbde_hip_gather_destroy(g);
     dbde_hip_destroy(ctx);
     printf("ok\n");

@@ -56,7 +56,12 @@ BIG = [  # BASELINE.json configs 2, 3, 4 at the bench seeds: hashes only
     # shapes whose kernel forms differ from the configs' (round 3): portrait HD, 1366x768, 16-byte rows that are not
     # whole cache lines, frames of 81 / 144 tiles
     ("shape_1080x1920", 1920, 1080), ("shape_1366x768", 768, 1366), ("shape_1440x900", 900, 1440),
-    ("shape_720x1280", 1280, 720), ("shape_72x72", 72, 72), ("shape_96x96", 96, 96)]
+    ("shape_720x1280", 1280, 720), ("shape_72x72", 72, 72), ("shape_96x96", 96, 96),
+    # frames of 300 .. 1200 tiles (round 4: whole frames per workgroup up to ~700 tiles, staged loads and stores)
+    ("shape_160x120", 120, 160), ("shape_176x144", 144, 176), ("shape_320x240", 240, 320)]
+# bench.py --gpus N: rank r round-trips frames r * 1024 .. r * 1024 + 1023 of the headline shape; every rank is held to
+# the reference's SHA-256 of ITS frames 0 and 3 (rank 0's are the cfg2 entries above)
+RANK_FRAMES = [r * 1024 + d for r in range(1, 8) for d in (0, 3)]
 
 
 def sha(a):
@@ -168,6 +173,16 @@ def main():
                 manifest["big"].append({"name": name, "mode": mname, "frame": frame, "H": H, "W": W,
                                         "image_sha": sha(img), "packed_sha": sha(packed),
                                         "packed_bytes": int(len(packed)), "depth_hist": hist})
+
+    for mname in ("noise8", "mixed"):
+        for frame in RANK_FRAMES:
+            W, H = 4096, 3072
+            img = ora.synth_frame(MODES[mname], SEED, frame, W, H)
+            packed = ref.pack_frame(frame, img, W, H)
+            hist = np.bincount(packed[24:24 + (W // 8) * (H // 8)], minlength=9).tolist()
+            manifest["big"].append({"name": "cfg2_rank_frames", "mode": mname, "frame": frame, "H": H, "W": W,
+                                    "image_sha": sha(img), "packed_sha": sha(packed),
+                                    "packed_bytes": int(len(packed)), "depth_hist": hist})
 
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **arrays)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:

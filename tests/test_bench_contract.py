@@ -94,3 +94,22 @@ def test_world_size_must_match_gpus_flag():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                        capture_output=True, text=True, env=e, timeout=120)
     assert r.returncode != 0 and "--gpus 2" in r.stderr
+
+
+def test_a_stuck_exchange_leaves_non_zero_with_the_line_printed():
+    """A rank that never answers a collective of the exchange leg: rank 0's watchdog prints the line it has (with the
+    error in it) and the run ends NON-ZERO -- a launcher must not read a hung exchange as success."""
+    r = run_bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run",
+                  env={"DBDE_BENCH_DRY_FAIL": "skip_gather", "DBDE_BENCH_WATCHDOG_S": "8"})
+    assert r.returncode != 0, (r.stdout, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "error" in d["gather"] and d["gathered_bytes"] is None
+
+
+def test_bench_source_leaves_non_zero_on_exchange_failure():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os._exit(0)" not in src, "a process that gave up on an exchange must not leave with 0"
+    assert src.count("os._exit(EXIT_EXCHANGE_FAILED)") >= 2      # the watchdog and the failed-gather path
+    assert "packed_sha_ok_ranks" in src                          # every rank is held to the reference SHA

@@ -277,6 +277,45 @@ def test_index_stream_speculative_walk(codec, oracle):
     assert cnt == n and torch.equal(found, offs)
 
 
+def test_config3_at_its_stated_size(codec, oracle, golden):
+    """BASELINE.json configs[2] as it is stated: a 1000-frame 2048x2048 stream, mixed depths 0-8, one concatenated
+    body, read the way the reference's walker reads a file (dbde_util.cpp:408-421: sizes are only in-band) -- the device
+    scanner finds the frame starts, one decode launch takes its offsets from there.  Offsets == the encoder's, count ==
+    1000, frames 0 / 3 against the REAL reference's SHA-256, three more frames byte for byte against the oracle, round
+    trip equal -- what bench.py asserts on this config, as a test."""
+    import torch
+    manifest, _ = golden
+    W, H, n = 2048, 2048, 1000
+    imgs = codec.synth_frames("mixed", SEED, 0, n, W, H)
+    buf, lead, cap = codec.alloc_stream(W, H, n)
+    offs, sizes = codec.encode_frames(imgs, W, H, n, buf, lead, cap, first_index=0)
+    codec.sync()
+    o, s = offs.cpu().numpy(), sizes.cpu().numpy()
+    assert o[0] == 0 and (o[1:] == (o + s)[:-1]).all(), "frames not concatenated"
+    total = int(o[-1] + s[-1])
+    # a reader's view: the bytes and their total length only
+    found = torch.empty(n + 8, dtype=torch.int64, device=imgs.device)
+    count = torch.zeros(1, dtype=torch.int32, device=imgs.device)
+    codec.index_stream_async(buf, lead, total, W, H, n + 8, found, count)
+    back, res = codec.decode_frames(buf, lead, total, found, W, H, n)
+    codec.sync()
+    assert int(count.item()) == n and torch.equal(found[:n], offs) and (found[n:] == -1).all()
+    assert torch.equal(back, imgs)
+    for f, (u64s, index, el, consumed) in enumerate(codec.parse_results(res)):
+        assert (u64s, index, el, consumed) == (2, f, 0, int(s[f])), f
+    checked = 0
+    for e in [e for e in manifest["big"] if e["name"] == "cfg3_2048x2048" and e["mode"] == "mixed"]:
+        f = e["frame"]
+        got = buf[lead + int(o[f]):lead + int(o[f] + s[f])].cpu().numpy()
+        assert len(got) == e["packed_bytes"] and sha(got) == e["packed_sha"], f
+        checked += 1
+    assert checked == 2
+    for f in (1, 499, n - 1):
+        want = oracle.pack_frame(f, oracle.synth_frame(MODES["mixed"], SEED, f, W, H), W, H)
+        got = buf[lead + int(o[f]):lead + int(o[f] + s[f])].cpu().numpy()
+        assert got.tobytes() == want.tobytes(), f
+
+
 def test_scan_ahead_reader_pipeline(codec):
     """dbde_hip_scan_ahead / dbde_hip_scan_join: an un-indexed stream read a batch at a time, the walk of the next
     batch on the context's second stream beside the decode of the current one; uneven last batch, cursor carried
@@ -447,7 +486,8 @@ def test_uniform_depth_content(codec, oracle, d):
 
 
 @pytest.mark.parametrize("name", ["cfg2_4096x3072", "cfg3_2048x2048", "cfg4_1921x1081", "shape_1080x1920", "shape_1366x768",
-                                  "shape_1440x900", "shape_720x1280", "shape_72x72", "shape_96x96"])
+                                  "shape_1440x900", "shape_720x1280", "shape_72x72", "shape_96x96",
+                                  "shape_160x120", "shape_176x144", "shape_320x240", "cfg2_rank_frames"])
 def test_baseline_configs_full_size(codec, golden, name):
     """BASELINE.json configs 2-4 and the shapes whose kernel forms differ from theirs (portrait HD, 1366x768, 16-byte
     rows that are not whole cache lines, frames of 81 / 144 tiles): packed-frame hashes equal the REAL reference's

@@ -53,7 +53,7 @@ C_ABI_SYMBOLS = [
     "dbde_hip_scatter_create", "dbde_hip_scatter_attach", "dbde_hip_scatter_destroy", "dbde_hip_scatter_error",
     "dbde_hip_scatter_set_max_message", "dbde_hip_scatter_set_capacity", "dbde_hip_scatter_begin", "dbde_hip_scatter_post",
     "dbde_hip_scatter_join", "dbde_hip_scatter_sync", "dbde_hip_scatter_blocks", "dbde_hip_scatter_check",
-    "dbde_hip_scatter_plan",
+    "dbde_hip_scatter_plan", "dbde_hip_create_on_own_stream", "dbde_hip_set_host_staging",
 ]
 
 

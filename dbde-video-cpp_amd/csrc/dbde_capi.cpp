@@ -36,6 +36,7 @@ struct Geometry {
 struct dbde_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = false;         // dbde_hip_create_on_own_stream: destroyed with the context
     std::string err;
     std::string arch;
 
@@ -74,6 +75,17 @@ struct dbde_hip_ctx {
     size_t st_img_bytes = 0;
     uint8_t *st_pack = nullptr;
     size_t st_pack_bytes = 0;
+    // ... and their pinned host twins (dbde_hip_set_host_staging): the caller's pageable bytes are copied through these
+    // by the calling thread, so that the DMA never has to pin (and the runtime's pinning of pageable memory, which
+    // serialises concurrent callers, is out of the way)
+    uint64_t *h_words = nullptr;     // pinned, device-visible: [0] the encoder's byte count, [1..4] the decoder's frame result -- the kernels write them
+                                     // straight into host memory, so a call has no small copies between its two big ones
+    uint8_t *d_hdr = nullptr;        // a frame header {2, 0, 0} in device memory (dbde_hip_unpack_image puts it in front of the caller's frame data)
+    int host_staging = 0;
+    uint8_t *h_img = nullptr;
+    size_t h_img_bytes = 0;
+    uint8_t *h_pack = nullptr;
+    size_t h_pack_bytes = 0;
     // timing
     uint32_t exp_flags = 0;          // $DBDE_HIP_EXPERIMENT (tuning experiments only)
     uint32_t enc_grid = 0;           // resident workgroups for the persistent encoder
@@ -157,10 +169,46 @@ void put64(uint8_t *p, uint64_t v) { for (int i = 0; i < 8; i++) p[i] = (uint8_t
 uint32_t get32(const uint8_t *p) { uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)p[i] << (8 * i); return v; }
 uint64_t get64(const uint8_t *p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i); return v; }
 
+int grow_pinned(dbde_hip_ctx *ctx, uint8_t *&p, size_t &have, size_t want) {
+    if (want <= have) return DBDE_HIP_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (p) HIP_TRY(ctx, hipHostFree(p));
+    p = nullptr;
+    have = 0;
+    void *q = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(&q, want + want / 4 + 64, hipHostMallocDefault));
+    p = reinterpret_cast<uint8_t *>(q);
+    have = want + want / 4 + 64;
+    return DBDE_HIP_OK;
+}
+
 int ensure_staging(dbde_hip_ctx *ctx, size_t img_bytes, size_t pack_bytes) {
+    if (!ctx->h_words) {
+        void *q = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(&q, 64, hipHostMallocDefault));
+        ctx->h_words = reinterpret_cast<uint64_t *>(q);
+        memset(ctx->h_words, 0, 64);
+        HIP_TRY(ctx, hipMalloc(&q, 32));
+        ctx->d_hdr = reinterpret_cast<uint8_t *>(q);
+        uint8_t hdr[20];
+        const dbde_hip_frame_header fh = {2, 0, 0};
+        dbde_hip_pack_frame_header(&fh, hdr);
+        HIP_TRY(ctx, hipMemcpy(ctx->d_hdr, hdr, 20, hipMemcpyHostToDevice));   // (once per context)
+    }
     int rc = grow(ctx, ctx->st_img, ctx->st_img_bytes, img_bytes + 64, 1);
     if (rc) return rc;
-    return grow(ctx, ctx->st_pack, ctx->st_pack_bytes, pack_bytes + 64, 1);
+    rc = grow(ctx, ctx->st_pack, ctx->st_pack_bytes, pack_bytes + 64, 1);
+    if (rc || !ctx->host_staging) return rc;
+    rc = grow_pinned(ctx, ctx->h_img, ctx->h_img_bytes, img_bytes + 64);
+    if (rc) return rc;
+    return grow_pinned(ctx, ctx->h_pack, ctx->h_pack_bytes, pack_bytes + 64);
+}
+
+// Host -> device / device -> host of the host-pointer entry points: straight from / to the caller's (pageable) memory, or
+// through the context's pinned twin (host_staging).  `via`: the pinned buffer that shadows the device buffer.
+bool h2d(dbde_hip_ctx *ctx, void *d_dst, const void *src, size_t n, uint8_t *via) {
+    if (ctx->host_staging && via) { memcpy(via, src, n); src = via; }
+    return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
 }
 
 }  // namespace
@@ -206,6 +254,20 @@ int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out) {
     return DBDE_HIP_OK;
 }
 
+int dbde_hip_create_on_own_stream(int device, dbde_hip_ctx **out) {
+    if (!out) return DBDE_HIP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DBDE_HIP_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return DBDE_HIP_ERR_HIP;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return DBDE_HIP_ERR_HIP;
+    const int rc = dbde_hip_create(device, s, out);
+    if (rc != DBDE_HIP_OK) { (void)hipStreamDestroy(s); return rc; }
+    (*out)->own_stream = true;
+    return DBDE_HIP_OK;
+}
+
 void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -224,6 +286,11 @@ void dbde_hip_destroy(dbde_hip_ctx *ctx) {
     if (ctx->sticky) (void)hipFree(ctx->sticky);
     if (ctx->st_img) (void)hipFree(ctx->st_img);
     if (ctx->st_pack) (void)hipFree(ctx->st_pack);
+    if (ctx->h_words) (void)hipHostFree(ctx->h_words);
+    if (ctx->d_hdr) (void)hipFree(ctx->d_hdr);
+    if (ctx->h_img) (void)hipHostFree(ctx->h_img);
+    if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -237,6 +304,12 @@ int dbde_hip_sync(dbde_hip_ctx *ctx) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->sticky, 0, 4, ctx->stream));
         return fail(ctx, DBDE_HIP_ERR_DEVICE, "encode kernel: chunk look-back timed out");
     }
+    return DBDE_HIP_OK;
+}
+
+int dbde_hip_set_host_staging(dbde_hip_ctx *ctx, int pinned) {
+    if (!ctx) return DBDE_HIP_ERR_ARG;
+    ctx->host_staging = pinned ? 1 : 0;
     return DBDE_HIP_OK;
 }
 
@@ -920,35 +993,53 @@ int dbde16_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t 
 
 // ---- host-pointer entry points ---------------------------------------------------------------
 
+// Device -> host on the context's OWN stream (hipMemcpy would go through the null stream, where the calls of every thread
+// of a multi-threaded caller queue up behind each other).
+static bool d2h(dbde_hip_ctx *ctx, void *dst, const void *src, size_t n, uint8_t *via = nullptr) {
+    void *land = ctx->host_staging && via ? via : dst;
+    if (hipMemcpyAsync(land, src, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    if (land != dst) memcpy(dst, land, n);
+    return true;
+}
+
 // Encodes one host image through the GPU; returns the frame's byte count and leaves the
 // packed frame (header + data) in ctx->st_pack.  0 on failure.
 static size_t encode_one_host(dbde_hip_ctx *ctx, uint64_t index, const uint8_t *image, int W, int H) {
     Geometry g;
     if (!ctx || !image || !geometry(W, H, g)) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0;   // (the calling thread may never have touched this device)
     const size_t maxf = 32 + 66 * (size_t)g.T;
     if (ensure_staging(ctx, (size_t)g.pixels, maxf)) return 0;
-    if (hipMemcpyAsync(ctx->st_img, image, (size_t)g.pixels, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
-    uint64_t *d_bytes = ctx->scratch64 + 1;
+    if (!h2d(ctx, ctx->st_img, image, (size_t)g.pixels, ctx->h_img)) return 0;
+    // the byte count lands in pinned host memory, written by the kernel itself: nothing small travels between the image
+    // going in and the frame coming out (a copy of 8 bytes costs the link what a hundred kilobytes cost it)
+    volatile uint64_t *h_bytes = ctx->h_words;
+    *h_bytes = 0;
     if (dbde_hip_encode_frames(ctx, ctx->st_img, W, H, 1, index, nullptr, nullptr, ctx->st_pack, maxf, 0, nullptr,
-                               d_bytes) != DBDE_HIP_OK)
+                               const_cast<uint64_t *>(h_bytes)) != DBDE_HIP_OK)
         return 0;
-    uint64_t nbytes = 0;
-    if (hipMemcpyAsync(&nbytes, d_bytes, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0;
-    if (dbde_hip_sync(ctx) != DBDE_HIP_OK) return 0;
-    return (size_t)nbytes;
+    // One frame is a launch of the small, tiny or mid encoders, which cannot raise the sticky failure word (their waits
+    // end in a fallback); only a frame of more chunks than the device holds workgroups runs the persistent encoder
+    Geometry gg = g;
+    const EncPlan pl = plan_encode(gg, W, 1, reinterpret_cast<uintptr_t>(ctx->st_img), reinterpret_cast<uintptr_t>(ctx->st_pack), 0, ctx->enc_grid);
+    if (pl.kernel == 0) { if (dbde_hip_sync(ctx) != DBDE_HIP_OK) return 0; }
+    else if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;
+    const uint64_t nbytes = *h_bytes;
+    return nbytes <= maxf ? (size_t)nbytes : 0;
 }
 
 size_t dbde_hip_pack_frame(dbde_hip_ctx *ctx, uint64_t index, const uint8_t *image, int W, int H, uint8_t *target) {
     size_t n = encode_one_host(ctx, index, image, W, H);
     if (!n || !target) return 0;
-    if (hipMemcpy(target, ctx->st_pack, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (!d2h(ctx, target, ctx->st_pack, n, ctx->h_pack)) return 0;
     return n;
 }
 
 size_t dbde_hip_pack_image(dbde_hip_ctx *ctx, const uint8_t *image, int W, int H, uint8_t *target) {
     size_t n = encode_one_host(ctx, 0, image, W, H);
     if (n <= 20 || !target) return 0;
-    if (hipMemcpy(target, ctx->st_pack + 20, n - 20, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (!d2h(ctx, target, ctx->st_pack + 20, n - 20, ctx->h_pack)) return 0;
     return n - 20;
 }
 
@@ -962,7 +1053,7 @@ uint32_t dbde_hip_pack_8x8_partial(dbde_hip_ctx *ctx, const uint8_t *image, int 
     size_t n = encode_one_host(ctx, 0, dense, rm, dm);
     if (n < 34) return 0;
     uint8_t head[34 + 64];
-    if (hipMemcpy(head, ctx->st_pack, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (!d2h(ctx, head, ctx->st_pack, n)) return 0;
     // T = 1: header 20 | nb 4 | depth 1 | nm 4 | min 1 | n64 4 | payload
     const uint32_t depth = head[24], mn = head[29];
     if (target && depth) memcpy(target, head + 34, 8u * depth);
@@ -979,15 +1070,15 @@ uint32_t dbde_hip_pack_8x8(dbde_hip_ctx *ctx, const uint8_t *image, int stride, 
 static size_t decode_one_staged(dbde_hip_ctx *ctx, size_t staged_bytes, int W, int H) {
     Geometry g;
     if (!geometry(W, H, g)) return 0;
-    uint64_t *d_off = ctx->scratch64 + 2;
-    const uint64_t zero = 0;
-    if (hipMemcpyAsync(d_off, &zero, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
-    dbde_hip_frame_result *d_res = reinterpret_cast<dbde_hip_frame_result *>(ctx->st_pack + ((staged_bytes + 63) & ~(size_t)63));
-    if (dbde_hip_decode_frames(ctx, ctx->st_pack, staged_bytes, d_off, W, H, 1, ctx->st_img, d_res) != DBDE_HIP_OK) return 0;
-    dbde_hip_frame_result res;
-    if (hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0;
-    if (dbde_hip_sync(ctx) != DBDE_HIP_OK) return 0;
-    return res.consumed > 20 ? (size_t)(res.consumed - 20) : 0;
+    uint64_t *d_off = ctx->scratch64 + 2;   // a zero that lives in device memory (cleared when the context was made, never written)
+    // the frame's result record is written by the kernel straight into pinned host memory
+    volatile dbde_hip_frame_result *h_res = reinterpret_cast<volatile dbde_hip_frame_result *>(ctx->h_words + 1);
+    h_res->consumed = 0;
+    if (dbde_hip_decode_frames(ctx, ctx->st_pack, staged_bytes, d_off, W, H, 1, ctx->st_img,
+                               const_cast<dbde_hip_frame_result *>(h_res)) != DBDE_HIP_OK) return 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;   // (decode kernels have no sticky failure)
+    const uint64_t consumed = h_res->consumed;
+    return consumed > 20 ? (size_t)(consumed - 20) : 0;
 }
 
 size_t dbde_hip_unpack_image(dbde_hip_ctx *ctx, const uint8_t *packed, int W, int H, uint8_t *image) {
@@ -1000,15 +1091,14 @@ size_t dbde_hip_unpack_image(dbde_hip_ctx *ctx, const uint8_t *packed, int W, in
     const int32_t n64 = (int32_t)get32(packed + 8 + 2 * (size_t)g.T);
     if (n64 < 0 || (uint64_t)n64 > 8ull * g.T) return 0;   // cannot equal sum(depth) with depth <= 8
     const size_t body = 12 + 2 * (size_t)g.T + 8 * (size_t)n64;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
     if (ensure_staging(ctx, (size_t)g.pixels, 20 + body + 128)) return 0;
-    uint8_t hdr[20];
-    dbde_hip_frame_header fh = {2, 0, 0};
-    dbde_hip_pack_frame_header(&fh, hdr);
-    if (hipMemcpyAsync(ctx->st_pack, hdr, 20, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
-    if (hipMemcpyAsync(ctx->st_pack + 20, packed, body, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
+    // a frame header in front of the caller's frame data: device to device (a 20-byte copy from the stack was a trip over the link)
+    if (hipMemcpyAsync(ctx->st_pack, ctx->d_hdr, 20, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return 0;
+    if (!h2d(ctx, ctx->st_pack + 20, packed, body, ctx->h_pack)) return 0;
     const size_t used = decode_one_staged(ctx, 20 + body, W, H);
     if (!used) return 0;
-    if (hipMemcpy(image, ctx->st_img, (size_t)g.pixels, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (!d2h(ctx, image, ctx->st_img, (size_t)g.pixels, ctx->h_img)) return 0;
     return used;
 }
 

@@ -2,48 +2,100 @@
 //
 // Exports the same mangled symbols as the reference's dbde_util.o so that programs written
 // against the reference link unchanged (SURVEY.md 8b lists them).  Each function is one
-// forwarding call into libdbde_hip.so; the only state is the lazily created context.
+// forwarding call into libdbde_hip.so on a context leased from a pool (below).
 #include "../../include/dbde_util.h"
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "../../include/dbde_hip.h"
 
 namespace {
 
-std::mutex g_lock;
-dbde_hip_ctx *g_ctx = nullptr;
+// The reference has no global state: its functions touch their arguments only and may be called from any number of
+// threads at once (dbde_util.h:21-37, dbde_util.cpp:137-180, 291-328).  Round 3 funnelled every call through ONE context
+// behind ONE mutex: sixteen caller threads got the throughput of one, half of what PCIe carries.  Now a POOL of contexts,
+// each on a stream of its own: a call leases one for its duration (the mutex is held for the hand-over only), so calls of
+// different threads overlap -- the H2D copy of one with the kernels and the D2H copy of another, both directions of the
+// link busy -- up to $DBDE_HIP_SHIM_CONTEXTS (default 16) at a time; further callers wait for a context to come back.
+// Contexts are created on demand, on $DBDE_HIP_DEVICE, and live until the process ends.
+struct Pool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<dbde_hip_ctx *> idle;
+    int created = 0, limit = 0;
+    int pinned_from = 0;      // calls in flight from which a call stages through pinned memory ($DBDE_HIP_SHIM_PINNED_FROM; 0 = never, the default)
+};
+Pool g_pool;
 
-// One context per process, on $DBDE_HIP_DEVICE.  No device -> no codec: fail loudly.
-dbde_hip_ctx *ctx() {
-    if (g_ctx) return g_ctx;
+dbde_hip_ctx *make_context() {
     const char *dev = getenv("DBDE_HIP_DEVICE");
-    int rc = dbde_hip_create(dev ? atoi(dev) : 0, nullptr, &g_ctx);
-    if (rc != DBDE_HIP_OK || !g_ctx) {
+    dbde_hip_ctx *c = nullptr;
+    const int rc = dbde_hip_create_on_own_stream(dev ? atoi(dev) : 0, &c);
+    if (rc != DBDE_HIP_OK || !c) {   // no device -> no codec: fail loudly
         fprintf(stderr, "dbde_util (HIP): no usable gfx950 device (dbde_hip_create -> %d); "
                         "this build has no CPU path\n", rc);
         abort();
     }
-    return g_ctx;
+    return c;
 }
+
+// A context for the duration of one call.
+struct Lease {
+    dbde_hip_ctx *c = nullptr;
+    Lease() {
+        std::unique_lock<std::mutex> g(g_pool.m);
+        if (!g_pool.limit) {
+            const char *n = getenv("DBDE_HIP_SHIM_CONTEXTS");
+            g_pool.limit = n && atoi(n) > 0 ? atoi(n) : 16;
+            const char *pf = getenv("DBDE_HIP_SHIM_PINNED_FROM");
+            g_pool.pinned_from = pf ? atoi(pf) : 0;   // (measured on a 16-core slice of the host: the pinned path gains nothing, profiles/r04_shim_threads.jsonl)
+        }
+        for (;;) {
+            if (!g_pool.idle.empty()) {   // (the most recently used: its staging buffers are warm)
+                c = g_pool.idle.back();
+                g_pool.idle.pop_back();
+                stage(g_pool.created - (int)g_pool.idle.size());
+                return;
+            }
+            if (g_pool.created < g_pool.limit) { g_pool.created++; break; }
+            g_pool.cv.wait(g);
+        }
+        const int in_flight = g_pool.created - (int)g_pool.idle.size();
+        g.unlock();
+        c = make_context();   // (outside the lock: creating a context takes milliseconds)
+        stage(in_flight);
+    }
+    // One caller: the runtime moves pageable memory fastest by pinning it on the fly.  Many callers: that pinning is what
+    // they queue on (measured: 4096x3072 round trips stop scaling at 4 threads), so from `pinned_from` calls in flight a
+    // call copies through the context's own pinned buffers instead.
+    void stage(int in_flight) { dbde_hip_set_host_staging(c, g_pool.pinned_from > 0 && in_flight >= g_pool.pinned_from); }
+    ~Lease() {
+        { std::lock_guard<std::mutex> g(g_pool.m); g_pool.idle.push_back(c); }
+        g_pool.cv.notify_one();
+    }
+    Lease(const Lease &) = delete;
+    Lease &operator=(const Lease &) = delete;
+};
 
 }  // namespace
 
 uint32_t dbde_pack_8x8(uint8_t *image, int stride, uint8_t *target) {
-    std::lock_guard<std::mutex> g(g_lock);
-    return dbde_hip_pack_8x8(ctx(), image, stride, target);
+    Lease l;
+    return dbde_hip_pack_8x8(l.c, image, stride, target);
 }
 
 uint32_t dbde_pack_8x8_partial(uint8_t *image, int stride, int rightmargin, int downmargin, uint8_t *target) {
-    std::lock_guard<std::mutex> g(g_lock);
-    return dbde_hip_pack_8x8_partial(ctx(), image, stride, rightmargin, downmargin, target);
+    Lease l;
+    return dbde_hip_pack_8x8_partial(l.c, image, stride, rightmargin, downmargin, target);
 }
 
 size_t dbde_pack_image(uint8_t *image, int W, int H, uint8_t *target) {
-    std::lock_guard<std::mutex> g(g_lock);
-    return dbde_hip_pack_image(ctx(), image, W, H, target);
+    Lease l;
+    return dbde_hip_pack_image(l.c, image, W, H, target);
 }
 
 size_t dbde_pack_frame_header(frame_header fh, uint8_t *target) {
@@ -52,8 +104,8 @@ size_t dbde_pack_frame_header(frame_header fh, uint8_t *target) {
 }
 
 size_t dbde_pack_frame(uint64_t index, uint8_t *image, int W, int H, uint8_t *target) {
-    std::lock_guard<std::mutex> g(g_lock);
-    return dbde_hip_pack_frame(ctx(), index, image, W, H, target);
+    Lease l;
+    return dbde_hip_pack_frame(l.c, index, image, W, H, target);
 }
 
 size_t dbde_pack_video_header(video_header vh, uint8_t *target) {
@@ -62,19 +114,19 @@ size_t dbde_pack_video_header(video_header vh, uint8_t *target) {
 }
 
 void dbde_unpack_8x8(uint8_t depth, uint8_t minval, uint8_t *packed, size_t stride, uint8_t *image) {
-    std::lock_guard<std::mutex> g(g_lock);
-    dbde_hip_unpack_8x8(ctx(), depth, minval, packed, stride, image);
+    Lease l;
+    dbde_hip_unpack_8x8(l.c, depth, minval, packed, stride, image);
 }
 
 void dbde_unpack_8x8_partial(uint8_t depth, uint8_t minval, uint8_t *packed, size_t stride, int rightmargin,
                              int downmargin, uint8_t *image) {
-    std::lock_guard<std::mutex> g(g_lock);
-    dbde_hip_unpack_8x8_partial(ctx(), depth, minval, packed, stride, rightmargin, downmargin, image);
+    Lease l;
+    dbde_hip_unpack_8x8_partial(l.c, depth, minval, packed, stride, rightmargin, downmargin, image);
 }
 
 size_t dbde_unpack_image(uint8_t *packed, int W, int H, uint8_t *image) {
-    std::lock_guard<std::mutex> g(g_lock);
-    return dbde_hip_unpack_image(ctx(), packed, W, H, image);
+    Lease l;
+    return dbde_hip_unpack_image(l.c, packed, W, H, image);
 }
 
 frame_header dbde_unpack_frame_header(uint8_t **packed) {
@@ -87,8 +139,8 @@ frame_header dbde_unpack_frame_header(uint8_t **packed) {
 }
 
 frame_header dbde_unpack_frame(uint8_t **packed, int W, int H, uint8_t *image) {
-    std::lock_guard<std::mutex> g(g_lock);
-    dbde_hip_frame_header h = dbde_hip_unpack_frame(ctx(), packed, W, H, image);
+    Lease l;
+    dbde_hip_frame_header h = dbde_hip_unpack_frame(l.c, packed, W, H, image);
     frame_header fh;
     fh.u64s = h.u64s;
     fh.index = h.index;

@@ -66,6 +66,15 @@ typedef struct {
  * keeps ownership of it.  Workspace (look-back state, decode index, staging buffers for the
  * host-pointer entry points) is owned by the context and grown on demand. */
 int dbde_hip_create(int device, void *stream, dbde_hip_ctx **out);
+/* The same with a stream of the context's OWN (non-blocking, destroyed with it): what a caller without the HIP headers
+ * needs to run several contexts side by side -- the drop-in shim keeps a pool of these, one per calling thread at a
+ * time, so that the reference's re-entrant API (dbde_util.h:21-37: no global state) scales with the caller's threads. */
+int dbde_hip_create_on_own_stream(int device, dbde_hip_ctx **out);
+/* How the host-pointer entry points (dbde_hip_pack_frame ...) move the caller's bytes: 0 (default) straight from / to
+ * the caller's pageable memory (the runtime pins it per call: fastest for ONE caller, but that pinning serialises
+ * concurrent callers), 1 through pinned buffers of the context (a memcpy by the calling thread each way, DMA that never
+ * pins: scales with the number of calling threads).  The drop-in shim switches per call by how many calls are in flight. */
+int dbde_hip_set_host_staging(dbde_hip_ctx *ctx, int pinned);
 void dbde_hip_destroy(dbde_hip_ctx *ctx);
 /* Blocks until everything enqueued by this context has finished; returns
  * DBDE_HIP_ERR_DEVICE if a kernel raised its failure flag since the last call. */

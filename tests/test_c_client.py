@@ -77,3 +77,59 @@ def test_gather_client_runs_one_rank_rccl(tmp_path):
     exe = _build_gather(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+THREADS_SRC = os.path.join(ROOT, "tests", "c_client", "threads.cpp")
+
+
+def build_threads_client(out_dir):
+    """g++ only: the client sees include/dbde_util.h and links libdbde_util_hip.so, as a user of the reference would."""
+    import dbde_video_cpp_amd as dv
+    if not os.path.exists(dv.LIB_PATH):
+        dv.build()
+    exe = os.path.join(str(out_dir), "threads")
+    subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), THREADS_SRC,
+                    "-L", dv.PKG_DIR, "-ldbde_util_hip", "-Wl,-rpath," + dv.PKG_DIR, "-o", exe],
+                   check=True, capture_output=True, text=True)
+    return exe
+
+
+def write_thread_inputs(out_dir, W, H, n, mode, packer):
+    """n distinct synthetic frames and what `packer` (the real reference where it is built, else the oracle) makes of them."""
+    import numpy as np
+    from oracle_ffi import Oracle
+    ora = Oracle()
+    frames, expected = os.path.join(str(out_dir), "frames.bin"), os.path.join(str(out_dir), "expected.bin")
+    with open(frames, "wb") as f, open(expected, "wb") as e:
+        for t in range(n):
+            img = ora.synth_frame(mode, 0xDBDE2016, 77 + t, W, H)
+            f.write(img.tobytes())
+            packed = packer.pack_frame(1000 + t, img, W, H)
+            e.write(np.uint64(len(packed)).tobytes())
+            e.write(packed.tobytes())
+    return frames, expected
+
+
+def test_threads_client_builds(tmp_path):
+    exe = build_threads_client(tmp_path)
+    out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    assert "_Z15dbde_pack_framemPhiiS_" in out and "_Z17dbde_unpack_framePPhiiS_" in out   # the reference's own mangled symbols
+    assert "hip" not in out.lower().replace("dbde", ""), "a user of the drop-in needs neither the C-ABI nor the HIP runtime by name"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,threads,mode", [(200, 123, 8, 1), (1921, 1081, 6, 1), (64, 64, 12, 0)])
+def test_drop_in_api_from_many_threads(tmp_path, W, H, threads, mode):
+    """The reference's API called from several threads at once on distinct buffers (it is re-entrant: dbde_util.h:21-37):
+    every packed frame equals the REAL reference's bytes, every unpacked image its input, nothing is written behind a
+    frame -- with more threads than the shim may hold contexts (DBDE_HIP_SHIM_CONTEXTS=4), so that callers also queue."""
+    from oracle_ffi import Oracle, Reference
+    packer = Reference() if Reference.available() else Oracle()
+    exe = build_threads_client(tmp_path)
+    frames, expected = write_thread_inputs(tmp_path, W, H, threads, mode, packer)
+    for limit in ("4", "16"):
+        r = subprocess.run([exe, str(W), str(H), str(threads), "12", frames, expected], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, DBDE_HIP_SHIM_CONTEXTS=limit))
+        assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["mismatches"] == 0 and d["threads"] == threads

@@ -684,7 +684,10 @@ def main():
                 t = rec.get(f"cfg{args.config}_{content}", {})
                 if rec.get("kernels_sha") == kernels_fingerprint() and t.get("frames_per_launch") == B and t.get(dom[0]):
                     roofline["traffic"] = t[dom[0]]
-                    roofline["traffic_source"] = f"replayed: rocprofv3 --pmc passes of {rec.get('tag')} on these kernel sources"
+                    roofline["traffic_source"] = (f"replayed: rocprofv3 --pmc passes of {rec.get('tag')} taken at revision "
+                                                  f"{rec.get('revision', '?')}"
+                                                  + (f", re-keyed to these sources by profiles/rekey.py (instruction streams identical, isa {rec.get('isa_sha')})"
+                                                     if rec.get("rekeyed") else " on these kernel sources"))
             except Exception:
                 pass
         line.update({"value": r["frames_per_s"], "raw_pixel_GBps": r["raw_pixel_GBps"], "ms_per_step": r["ms_per_step"],
@@ -724,7 +727,9 @@ def main():
                                             (1366, 768, 4096, "odd rows: any-geometry encoder, 192-thread staged decode"),
                                             (1440, 900, 2048, "16-byte rows, not whole cache lines: direct 16-byte stores"),
                                             (720, 1280, 4096, "16-byte rows, whole-tile-row chunks: direct or staged per chunk"),
-                                            (72, 72, 262144, "81 tiles: whole frames per workgroup, both directions")):
+                                            (72, 72, 262144, "81 tiles: whole frames per workgroup (encode: staged through LDS, round 4)"),
+                                            (160, 120, 65536, "300 tiles: three whole frames per 512-thread workgroup on the encode side (round 4)"),
+                                            (320, 240, 16384, "1200 tiles: above the whole-frame forms, two chunks per frame")):
                     try:
                         r_ = strip(b.case(sw, sh_, sn, "mixed", "slots", max(3, sub_steps // 3), 1))
                         r_["workload"] = f"{sn} frames of {sw}x{sh_}, mixed, slots; {note}"

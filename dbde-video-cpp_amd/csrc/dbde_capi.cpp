@@ -420,8 +420,25 @@ struct EncPlan {
     bool fast_in, aligned_out;
     uint32_t enc_cpf, lanes_per_row, pairs_per_wave;
     uint64_t n_chunks64;
-    int kernel;            // 0 = persistent (encode_kernel), 1 = encode_small_kernel, 2 = encode_tiny_kernel, 3 = encode_mid_kernel
+    int kernel;            // 0 = persistent (encode_kernel), 1 = encode_small_kernel, 2 = encode_tiny_kernel, 3 = encode_mid_kernel, 4 = encode_frames_kernel
 };
+#ifndef DBDE_FRAMES_ENCODE_TILES
+// Frames of 65 .. this many tiles with 8-byte aligned rows encode / decode with whole frames per workgroup and staged,
+// coalesced traffic (encode_frames_kernel / decode_frames_kernel); above it the chunk kernels' 512 / 1024 tile slots are
+// filled well enough by one frame.
+#define DBDE_FRAMES_ENCODE_TILES 640   // measured (mixed, encode): 81 tiles 0.39 -> 0.51, 144 0.44 -> 0.56, 256 0.49 -> 0.65, 300 0.32 -> 0.51, 396 0.39 -> 0.57, 625 0.47 -> 0.48
+#endif
+#ifndef DBDE_FRAMES_DECODE_TILES
+// The decode side is built and tested ($DBDE_HIP_EXPERIMENT bit 8 switches it on) but NOT taken by default: against the
+// forms it would replace it measured equal at 81 tiles (0.39; incompressible 0.42 -> 0.49) and slower from 144 tiles on
+// (0.43 -> 0.37; 300 tiles: 0.55 with its index kernel counted -> 0.44) -- six dependent phases per workgroup, each a
+// memory or LDS round trip, where decode_mid_kernel and the chunk decoder have three.
+#define DBDE_FRAMES_DECODE_TILES 640
+#endif
+// rows 8-byte aligned, frames and base whole 16-byte blocks: what the staged whole-frame kernels take
+static bool frames_geometry(const Geometry &g, int W, uintptr_t images) {
+    return W % 8 == 0 && g.pixels % 16 == 0 && (images & 15u) == 0 && g.T > 64u;
+}
 static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t images, uintptr_t out, uint64_t slot_stride,
                            uint32_t enc_grid) {
     EncPlan pl;
@@ -451,6 +468,10 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
     pl.aligned_out = ((out & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
     pl.kernel = 0;
     if (g.T <= 64u && slot_stride != 0) pl.kernel = 2;          // tiny frames in slots: several frames per wave, nothing shared
+#ifndef DBDE_NO_FRAMES
+    else if (slot_stride != 0 && g.T <= (unsigned)DBDE_FRAMES_ENCODE_TILES && frames_geometry(g, W, images) && (out & 15u) == 0 &&
+             slot_stride % 16 == 0) pl.kernel = 4;              // 65 .. 700 tiles, aligned rows: whole frames per workgroup, staged
+#endif
 #ifndef DBDE_NO_MID
     else if (g.T <= (unsigned)DBDE_MID_ENCODE_TILES && slot_stride != 0) pl.kernel = 3;   // 65 .. 256 tiles in slots: whole frames per workgroup
 #endif
@@ -501,6 +522,13 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
         return DBDE_HIP_OK;
     }
 
+    if (pl.kernel == 4) {   // frames of 65 .. 700 tiles in slots, 8-byte aligned rows: whole frames per workgroup, staged (encode_frames_kernel)
+        span_begin(ctx, 0);
+        HIP_TRY(ctx, launch_encode_frames(p, (uint32_t)n_frames, ctx->stream));
+        span_end(ctx);
+        return DBDE_HIP_OK;
+    }
+
     if (pl.kernel == 3) {   // frames of 65 .. 256 tiles in slots: whole frames per workgroup (encode_mid_kernel)
         span_begin(ctx, 0);
         HIP_TRY(ctx, launch_encode_mid(p, (uint32_t)n_frames, ctx->stream));
@@ -545,7 +573,7 @@ struct DecPlan {
     DecGeom dg;
     uint64_t n_chunks64;
     bool self_index, fused;
-    int kernel;            // 0 = chunk kernels, 2 = decode_tiny_kernel, 3 = decode_mid_kernel
+    int kernel;            // 0 = chunk kernels, 2 = decode_tiny_kernel, 3 = decode_mid_kernel, 4 = decode_frames_kernel
 };
 static DecPlan plan_decode(const Geometry &g, int W, int n_frames, uintptr_t ib, int n_cu, uint32_t exp_flags) {
     DecPlan pl;
@@ -603,6 +631,9 @@ static DecPlan plan_decode(const Geometry &g, int W, int n_frames, uintptr_t ib,
     pl.fused = !pl.self_index && pl.n_chunks64 <= 4ull * (uint64_t)n_cu && !(exp_flags & 8u);
     // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup
     pl.kernel = g.T <= 64u ? 2 : (g.T <= (unsigned)DBDE_MID_DECODE_TILES ? 3 : 0);
+#ifndef DBDE_NO_FRAMES
+    if ((exp_flags & 256u) && g.T > 64u && g.T <= (unsigned)DBDE_FRAMES_DECODE_TILES && frames_geometry(g, W, ib)) pl.kernel = 4;
+#endif
     return pl;
 }
 
@@ -631,6 +662,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
         tp.W = W; tp.H = H; tp.w = g.w; tp.h = g.h; tp.T = g.T;
         span_begin(ctx, 2);
         if (pl.kernel == 2) HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
+        else if (pl.kernel == 4) HIP_TRY(ctx, launch_decode_frames(tp, (uint32_t)n_frames, ctx->stream));
         else HIP_TRY(ctx, launch_decode_mid(tp, (uint32_t)n_frames, ctx->stream));
         span_end(ctx);
         return DBDE_HIP_OK;
@@ -837,7 +869,7 @@ int dbde_hip_encode_plan(int W, int H, int n_frames, uint64_t image_address, uin
     plan->kernel = pl.kernel;
     plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? (pl.pairs_per_wave == 63u ? 3 : 1) : 2);
     plan->aligned_out = pl.aligned_out ? 1 : 0;
-    plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u));
+    plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u)));
     plan->chunks_per_frame = pl.kernel >= 2 ? 0u : pl.enc_cpf;
     plan->chunk_tiles = pl.kernel >= 2 ? 0u : (pl.lanes_per_row ? 2u * pl.pairs_per_wave * (kEncChunkTiles / 128u) : kEncChunkTiles);
     plan->n_chunks = pl.kernel >= 2 ? 0ull : pl.n_chunks64;
@@ -858,7 +890,7 @@ int dbde_hip_decode_plan(int W, int H, int n_frames, uint64_t image_address, int
         plan->chunk_tiles = pl.dg.ct;
         plan->n_chunks = pl.n_chunks64;
     } else {
-        plan->threads = pl.kernel == 2 ? 256 : (int32_t)mid_threads_for(g.T);
+        plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)mid_threads_for(g.T));
     }
     return DBDE_HIP_OK;
 }

@@ -168,6 +168,11 @@ int encode_blocks_per_cu();
 hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t s);
 uint32_t mid_threads_for(uint32_t T);
 hipError_t launch_decode_mid(const struct DecParams &p, uint32_t n_frames, hipStream_t s);
+// Frames of 65 .. 1024 tiles with 8-byte aligned rows, whole frames per workgroup, pixels and stream bytes staged through
+// LDS as aligned 16-byte blocks (encode: one slot per frame).  frames_threads_for: 256 or 512 threads (512 / 1024 tile slots).
+hipError_t launch_encode_frames(const EncParams &p, uint32_t n_frames, hipStream_t s);
+hipError_t launch_decode_frames(const struct DecParams &p, uint32_t n_frames, hipStream_t s);
+uint32_t frames_threads_for(uint32_t T);
 // Frames of at most 64 tiles, one slot per frame: one tile per lane, 64 / T frames per wave, no workspace.
 hipError_t launch_encode_tiny(const EncParams &p, uint32_t n_frames, hipStream_t s);
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);

@@ -78,6 +78,18 @@ def main():
     import bench
     cur["kernels_sha"] = bench.kernels_fingerprint()
     cur["tag"] = tag.split("_")[0]
+    # the revision the pass was taken at (profiles/rekey.py compares later sources against it; "+dirty": uncommitted edits)
+    try:
+        import subprocess
+        root = os.path.dirname(here)
+        rev = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "dbde-video-cpp_amd/csrc"], capture_output=True, text=True).stdout.strip()
+        if rev:
+            cur["revision"] = rev + ("+dirty" if dirty else "")
+    except Exception:
+        pass
+    cur.pop("rekeyed", None)
+    cur.pop("isa_sha", None)
     json.dump(cur, open(tf, "w"), indent=1)
     print("\n".join(out))
 

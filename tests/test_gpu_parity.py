@@ -751,7 +751,7 @@ def test_seeded_fuzz_against_oracle(codec, oracle):
 @pytest.mark.parametrize("W,H,n", [(8, 8, 1000), (64, 64, 300), (10, 10, 77), (33, 31, 50), (24, 16, 5), (1, 1, 9), (512, 8, 40),
                                    (7, 300, 33), (61, 59, 129)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
-def test_tiny_frames_many_per_wave(codec, oracle, W, H, n, mode):
+def test_tiny_frames_many_per_wave(codec, codec_staged_decode, oracle, W, H, n, mode):
     """Frames of at most 64 tiles (the reference's randomized test is 1024 single-tile frames, dbde_util_test.cpp:66-96):
     one tile per lane, several frames per wave in both directions (encode_tiny_kernel for slots, decode_tiny_kernel);
     every frame byte for byte against the oracle, both layouts, partial tiles, a frame count that leaves lanes idle."""
@@ -764,17 +764,22 @@ def test_tiny_frames_many_per_wave(codec, oracle, W, H, n, mode):
         for f in range(n):
             assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
         total = int((offs[-1] + sizes[-1]).item())
-        canvas = torch.full_like(imgs, 0xEE)
-        back, res = codec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
-        codec.sync()
-        assert torch.equal(back, imgs), (W, H, mode, slot)
-        assert codec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
+        for dec in (codec, codec_staged_decode):      # the default forms, and the staged whole-frame decoder where it applies
+            canvas = torch.full_like(imgs, 0xEE)
+            back, res = dec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
+            dec.sync()
+            assert torch.equal(back, imgs), (W, H, mode, slot)
+            assert dec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
 
 
 @pytest.mark.parametrize("W,H,n", [(72, 72, 200), (96, 96, 150), (128, 128, 64), (160, 120, 90), (71, 73, 100), (176, 144, 41),
-                                   (520, 8, 30), (9, 600, 25), (180, 180, 7), (130, 121, 1), (65, 64, 513)])
+                                   (520, 8, 30), (9, 600, 25), (180, 180, 7), (130, 121, 1), (65, 64, 513),
+                                   # round 4, the staged whole-frame kernels (8-byte rows): odd tile counts, rows below the image
+                                   # repeated (H % 8 != 0), one frame per workgroup, a last workgroup that is part empty
+                                   (72, 72, 7), (104, 100, 33), (200, 150, 19), (168, 161, 10), (224, 200, 5), (176, 144, 1),
+                                   (520, 65, 9), (8, 5200, 3)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
-def test_mid_frames_many_per_workgroup(codec, oracle, W, H, n, mode):
+def test_mid_frames_many_per_workgroup(codec, codec_staged_decode, oracle, W, H, n, mode):
     """Frames of 65 .. 512 tiles (72 .. 180 pixels a side): one tile per lane, as many whole frames per 256 / 512 / 1024
     thread workgroup as fit (encode_mid_kernel for slots; decode_mid_kernel where it is the faster form); every frame
     byte for byte against the oracle, both layouts, partial tiles, frame counts that leave the last workgroup part empty."""
@@ -787,11 +792,79 @@ def test_mid_frames_many_per_workgroup(codec, oracle, W, H, n, mode):
         for f in range(n):
             assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
         total = int((offs[-1] + sizes[-1]).item())
+        for dec in (codec, codec_staged_decode):      # the default forms, and the staged whole-frame decoder where it applies
+            canvas = torch.full_like(imgs, 0xEE)
+            back, res = dec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
+            dec.sync()
+            assert torch.equal(back, imgs), (W, H, mode, slot)
+            assert dec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
+
+
+@pytest.fixture(scope="module")
+def codec_staged_decode(dv):
+    """A context whose decode calls take decode_frames_kernel where the geometry allows ($DBDE_HIP_EXPERIMENT bit 8: the
+    staged whole-frame decoder is built and correct but not the default, it measured no faster)."""
+    import os
+    old = os.environ.get("DBDE_HIP_EXPERIMENT")
+    os.environ["DBDE_HIP_EXPERIMENT"] = str(256 | int(old or "0", 0))
+    c = dv.Codec(0)
+    if old is None:
+        del os.environ["DBDE_HIP_EXPERIMENT"]
+    else:
+        os.environ["DBDE_HIP_EXPERIMENT"] = old
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("which", ["default", "staged"])
+@pytest.mark.parametrize("W,H,n", [(72, 72, 50), (160, 120, 23), (96, 96, 61), (200, 150, 9)])
+def test_staged_frame_decoder_takes_any_offsets_and_rejects_like_the_reference(codec, codec_staged_decode, oracle, W, H, n, which):
+    codec = codec if which == "default" else codec_staged_decode
+    """decode_frames_kernel: frames wherever they lie (concatenated: every alignment mod 16; a stream base that is odd), a
+    readable extent that ends with the last frame, and malformed frames among good ones -- nb / nm / n64 wrong, a depth
+    byte above 8, a truncated frame, a wild offset: rejected with u64s = 0xFFFFFFFF and consumed = 20 (dbde_util.cpp:
+    295-303, 335, 342), their images untouched, their neighbours decoded."""
+    import torch
+    T = ((W + 7) // 8) * ((H + 7) // 8)
+    imgs = codec.synth_frames("mixed", SEED, 3, n, W, H)
+    imgs_h = imgs.cpu().numpy()
+    for misalign in (0, 1, 6):
+        frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=3, slot_stride=0, misalign=misalign)
+        for f in (0, n // 2, n - 1):
+            assert frames[f].tobytes() == oracle.pack_frame(3 + f, imgs_h[f], W, H).tobytes()
+        total = int((offs[-1] + sizes[-1]).item())
         canvas = torch.full_like(imgs, 0xEE)
-        back, res = codec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
+        back, res = codec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)      # extent ends with the last frame
         codec.sync()
-        assert torch.equal(back, imgs), (W, H, mode, slot)
-        assert codec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
+        assert torch.equal(back, imgs), (W, H, misalign)
+        o, s_ = offs.cpu().numpy(), sizes.cpu().numpy()
+        bad = buf.clone()
+        victims = {}
+        def poke(f, pos, delta):
+            a = lead + int(o[f]) + pos
+            bad[a] = (int(bad[a].item()) + delta) % 256
+        if n >= 9:
+            poke(1, 20, 1); victims[1] = "nb"
+            poke(2, 24 + T, 1); victims[2] = "nm"
+            poke(4, 28 + 2 * T, 1); victims[4] = "n64"
+            a = lead + int(o[5]) + 24
+            bad[a] = 9; victims[5] = "depth 9"
+            poke(7, 0, 1); victims[7] = "frame field"          # header field wrong: the image IS decoded (dbde_util.cpp:339-345), u64s = -1
+        offs_bad = offs.clone()
+        offs_bad[n - 1] = total - 5                                # a frame that starts 5 bytes before the end of the extent
+        victims[n - 1] = "truncated"
+        canvas = torch.full_like(imgs, 0xEE)
+        back, res = codec.decode_frames(bad, lead, total, offs_bad, W, H, n, images=canvas)
+        codec.sync()
+        rs = codec.parse_results(res)
+        for f in range(n):
+            why = victims.get(f)
+            if why is None:
+                assert torch.equal(back[f], imgs[f]) and rs[f] == (2, 3 + f, 0, int(s_[f])), (f, rs[f])
+            elif why == "frame field":
+                assert rs[f][0] == 0xFFFFFFFF and torch.equal(back[f], imgs[f]), (f, rs[f])
+            else:
+                assert rs[f][0] == 0xFFFFFFFF and rs[f][3] == 20 and bool((back[f] == 0xEE).all()), (f, why, rs[f])
 
 
 @pytest.mark.parametrize("W,H,n,mode,concat", [(1921, 1081, 64, "noise8", True), (2048, 1024, 70, "mixed", False),

@@ -349,6 +349,7 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
     p.ctrl = nullptr;
     p.ctrl_next = nullptr;
     p.mode_flags = nullptr;
+    p.arrive_flags = nullptr;
     p.launch_epoch = 0;
     p.sticky = ctx->sticky;
     p.slot_stride = slot_stride;
@@ -379,8 +380,8 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
 // The block is zeroed when it is (re)allocated, when the small launches' epoch wraps, and after a launch that failed
 // (dbde_hip_sync saw the sticky word: until then the context's launches return at once, encode_kernel).
 static int attach_lookback(dbde_hip_ctx *ctx, EncParams &p, uint32_t n_chunks, bool small) {
-    // two sets of control words | the mode flags | records
-    constexpr size_t kFlagsAt = 2 * 4 * (size_t)kEncCtrlWords, kHeader = (kFlagsAt + 4 * (size_t)kEncMaxGrid + 4095) & ~(size_t)4095;
+    // two sets of control words | the mode flags | the arrival flags | records
+    constexpr size_t kFlagsAt = 2 * 4 * (size_t)kEncCtrlWords, kHeader = (kFlagsAt + 2 * 4 * (size_t)kEncMaxGrid + 4095) & ~(size_t)4095;
     const size_t lb_need = (kHeader + 8 * (size_t)n_chunks + 15) & ~(size_t)15;
     {   // grown in place: on failure ctx->lb is null and ctx->lb_bytes 0, never a freed pointer
         const size_t had = ctx->lb_bytes;
@@ -400,6 +401,7 @@ static int attach_lookback(dbde_hip_ctx *ctx, EncParams &p, uint32_t n_chunks, b
     p.ctrl = reinterpret_cast<uint32_t *>(ctx->lb) + kEncCtrlWords * ctx->enc_parity;
     p.ctrl_next = reinterpret_cast<uint32_t *>(ctx->lb) + kEncCtrlWords * (ctx->enc_parity ^ 1u);
     p.mode_flags = reinterpret_cast<uint32_t *>(ctx->lb + kFlagsAt);
+    p.arrive_flags = p.mode_flags + kEncMaxGrid;
     p.state = reinterpret_cast<unsigned long long *>(ctx->lb + kHeader);
     if (!small) ctx->enc_parity ^= 1u;
     return DBDE_HIP_OK;

@@ -77,7 +77,7 @@ inline uint32_t div_magic_of(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint3
 #ifndef DBDE_CTRL_SLOT_WORDS
 #define DBDE_CTRL_SLOT_WORDS 64                 // u32 between two counters of the persistent encoder's control words: a 256-byte slot each (A/B: 4 KB slots measured the same)
 #endif
-constexpr uint32_t kEncCtrlWords = 2 * 16 * DBDE_CTRL_SLOT_WORDS + 1024;   // u32 per set of control words: 16 arrival + 16 tail-ticket counters, a slot each, + the rest
+constexpr uint32_t kEncCtrlWords = 16 * DBDE_CTRL_SLOT_WORDS + 1024;   // u32 per set of control words: 16 tail-ticket counters, a slot each, + the rest
 constexpr uint32_t kEncMaxGrid = 4096;          // workgroups the mode flags have room for (dbde_capi.cpp: the look-back block's header)
 
 struct EncParams {
@@ -92,6 +92,7 @@ struct EncParams {
     uint32_t *ctrl;                // this launch's control words (kEncCtrlWords u32: group arrival / tail-ticket counters, mode, ticket counter; dbde_kernels.hip), zero when the launch starts
     uint32_t *ctrl_next;           // the NEXT launch's set (the host alternates between two): cleared by the scanner
     uint32_t *mode_flags;          // [grid] one word per workgroup: launch_epoch << 2 | claim mode, written by whoever settles the mode
+    uint32_t *arrive_flags;        // [grid] one word per workgroup: launch_epoch << 2 | 1, written by the workgroup when it starts
     uint32_t launch_epoch;         // 1 .. 2^30 - 1: tag of THIS persistent launch's mode flags (never cleared between launches)
     uint32_t *sticky;              // context-wide failure word, OR-ed on look-back time-out
     uint64_t slot_stride;          // 0 = frames concatenated

@@ -353,6 +353,22 @@ __device__ __forceinline__ void scanner_loop(const EncParams &p, int lane) {
 #endif
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vector memory (vmcnt(0): loads and stores
+// share one counter on this part), i.e. it waits for every pixel the wave has requested -- in the encoder's prologue that is
+// the launch's first 32 MB burst, 6-12 us, and the claim mode was being waited for BEHIND it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// One uncached dword through the SCALAR unit (glc: past the scalar cache): its result does not queue behind the wave's
+// outstanding vector loads, which return in issue order.
+__device__ __forceinline__ uint32_t scalar_load_uncached(const uint32_t *ptr) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+}
+
 // Scout side: wait until the scanner has converted this chunk's own record.
 __device__ __forceinline__ bool wait_inc(const u64a *state, uint32_t c, uint32_t &inf_incl, uint32_t &glob_incl,
                                          uint32_t *n_polls = nullptr) {
@@ -401,13 +417,11 @@ __device__ __forceinline__ bool wait_inc(const u64a *state, uint32_t c, uint32_t
 // the smallest unfinished chunk can always finish.
 constexpr int kEncWaves = kEncChunkTiles / 128;                  // two tiles per lane
 // control words of a persistent launch (EncParams::ctrl, a set of kCtrlWords u32, zero when the launch starts)
-// Sixteen arrival counters and sixteen tail-ticket counters (workgroup b uses counter b % 16), each ALONE in a 256-byte
-// slot: read-modify-writes to one 64-byte line retire one after the other whichever word they address (16 counters side
-// by side in one line measured no better than one counter: the first arrival number came back after 4.5 .. 13 us).
+// Sixteen tail-ticket counters (workgroup b uses counter b % 16), each in a 256-byte slot of its own; the verdict, the
+// scanner's role and the ticket counter of the fallback behind them.
 constexpr uint32_t kEncGroups = 16, kCtrlSlot = DBDE_CTRL_SLOT_WORDS;   // (slot stride in u32)
-constexpr uint32_t kCtrlArrive = 0, kCtrlTail = kEncGroups * kCtrlSlot, kCtrlVerdict = 2u * kEncGroups * kCtrlSlot,
-                   kCtrlTickets = kCtrlVerdict + 2u /* u64, 8-byte aligned */;
-constexpr uint32_t kVerdictTimeout = 0x100u;                     // verdict word: groups complete in 7:0, this bit = somebody timed out
+constexpr uint32_t kCtrlTail = 0, kCtrlVerdict = kEncGroups * kCtrlSlot /* 0 = open, 1 = static, 2 = tickets */,
+                   kCtrlScanner = kCtrlVerdict + 1u /* the scanner's role: 0 = free */, kCtrlTickets = kCtrlVerdict + 2u;
 static_assert(kCtrlTickets + 2u <= kEncCtrlWords, "control words do not fit their set");
 constexpr int kEncThreads = 64 * kEncWaves;
 constexpr uint32_t kWaveWords = 128 * 8;                         // 1024 U64 = 8 KiB per wave
@@ -846,104 +860,142 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
     }
 #endif
 
-    // Roles, ranks and the claim mode.  Read-modify-writes on ONE address retire at about 15 ns each on this part, whoever
-    // issues them (in-kernel timeline, -DDBDE_DIAG): round 3's prologue -- 512 arrivals on one counter, then 511 pollers on
-    // one word until all had been seen -- held every launch for 22 us with a single chunk of loads in flight, and handing
-    // the first rounds out as tickets from one counter cost as much again (12-14 us steps instead of 9).  So:
-    //   * arrivals are counted in 16 GROUP counters (workgroup b adds to counter b % 16: 32 contenders per address) and
-    //     the value drawn gives the arrival number R = v * 16 + b % 16 -- dense 0 .. G once everybody has arrived;
-    //   * R == 0 is the SCANNER (one of its waves runs the in-order scan, the others retire): the first of its group to
-    //     run, a running workgroup by construction.  Any other R encodes, with rank R - 1, and fetches chunk `rank` at once;
-    //   * the last arrival of a group bumps a second-level counter; whoever completes it has seen ALL G + 1 workgroups
-    //     running and settles the launch's mode -- STATIC strides (chunk = rank + k G, no atomics: only safe
-    //     when every encoding workgroup runs) -- and TELLS everybody: its 512 threads write one flag per workgroup
-    //     (tagged with the launch's epoch, so flags are never cleared).  A workgroup polls only its OWN flag;
-    //   * a flag that has not come after 20 us (oversubscribed device: somebody is not running) sets the time-out bit of
-    //     that second-level word -- whichever of the two read-modify-writes comes first decides -- and the verdict is TICKETS: every chunk id, the first included, is then drawn from one counter by a
-    //     workgroup that is running -- dense in draw order, forward progress whatever the dispatch order (a
-    //     single-address ticket per chunk costs 6-13 % at full speed, which is why it is the fallback).
+    // Roles, ranks and the claim mode -- settled without a single read-modify-write on the way to the first pixels.
+    // What the prologue costs was read off the in-kernel timeline (-DDBDE_DIAG, profiles/abbench): round 3 -- arrivals on one
+    // counter, then 511 pollers on one word until all had been seen -- held every launch for 22 us with one chunk of loads in
+    // flight; 16 group counters in slots of their own still 17 us, because a workgroup's FIRST read-modify-write of a launch
+    // comes back after 8 us on average (14 at worst) whatever it addresses, and the chunk id waited for it.  Now:
+    //   * workgroup b > 0 ENCODES with rank b - 1: it announces itself with a plain store (arrive_flags[b], tagged with the
+    //     launch's epoch: never cleared) and fetches chunk `rank` at once -- nothing to wait for;
+    //   * workgroup 0 CHECKS and then SCANS: one wave sweeps the arrival flags; when every one of the G encoders has been
+    //     seen running it settles the launch's mode with a CAS -- STATIC strides (chunk = rank + k G, no atomics: only safe
+    //     when every encoding workgroup runs) -- and its 512 threads TELL everybody (one mode flag per workgroup, epoch-tagged
+    //     as well; a workgroup polls only its OWN flag).  It then claims the scanner's role and runs the in-order scan;
+    //   * a mode flag that has not come after 20 us (oversubscribed device: somebody -- workgroup 0, perhaps -- is not
+    //     running) ends in the same CAS with the other verdict, TICKETS: every chunk id, the first included, is then drawn
+    //     from one counter by a workgroup that is running -- dense in draw order, forward progress whatever the dispatch
+    //     order (a single-address ticket per chunk costs 6-13 % at full speed, which is why it is the fallback).  Whoever
+    //     decides so tells the others and, when workgroup 0 has not announced itself, claims the scanner's role in its
+    //     place (the role is one CAS: exactly one workgroup scans, and it is one that runs).  A workgroup 0 that finds the
+    //     role taken encodes like the others.
     const uint32_t G = gridDim.x - 1u;              // workgroups that encode
-    const uint32_t n_grp = gridDim.x < kEncGroups ? gridDim.x : kEncGroups, grp = blockIdx.x % kEncGroups;
+    const uint32_t n_grp = gridDim.x < kEncGroups ? gridDim.x : kEncGroups, grp = blockIdx.x % kEncGroups;   // (tail tickets)
     const uint32_t tag = p.launch_epoch << 2;
-    u64a *const tickets = reinterpret_cast<u64a *>(p.ctrl + kCtrlTickets);
+    uint32_t *const tickets = p.ctrl + kCtrlTickets;
     if (tid == 0) {
         // (a context whose sticky failure word is set has records in an unknown state: its launches do nothing until
-        // dbde_hip_sync has reported the failure and the host has cleared the workspace)
-        // (a plain load: the word was last written by an EARLIER kernel, so the caches are good for it -- as an agent-scope
-        // atomic load it went to the memory side, where 512 reads of one address queued up for 13 us)
+        // dbde_hip_sync has reported the failure and the host has cleared the workspace.  A plain load: the word was last
+        // written by an EARLIER kernel, so the caches are good for it)
         const uint32_t dead = *p.sticky;
-        const uint32_t v = atomicAdd(&p.ctrl[kCtrlArrive + grp * kCtrlSlot], 1u);
-#ifdef DBDE_DIAG
-        sh.dg[0] = v == 0xFFFFFFFFu ? 0ull : (uint64_t)wall_clock64();   // (the arrival number has come back)
-#endif
-        uint32_t tell = 0u;
-        if (v + 1u == (gridDim.x - grp + kEncGroups - 1u) / kEncGroups) {               // the last of its group ...
-            const uint32_t old = atomicAdd(&p.ctrl[kCtrlVerdict], 1u);
-            if (!(old & kVerdictTimeout) && (old & 0xFFu) + 1u == n_grp)                  // ... and of the groups, in time
-                tell = (p.flags & 1u) ? 2u : 1u;
-        }
-        sh.boot[0] = dead ? 0xFFFFFFFFu : v * kEncGroups + grp;
-        sh.boot[1] = tell;
+        if (!dead) __hip_atomic_store(&p.arrive_flags[blockIdx.x], tag | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.boot[0] = dead;
+        sh.boot[1] = 0u;
         sh.acc[0] = 0; sh.acc[1] = 0;
     }
     __syncthreads();
-    const uint32_t arrival = __builtin_amdgcn_readfirstlane(sh.boot[0]);
-    if (arrival == 0xFFFFFFFFu) return;
-    {
-        const uint32_t tell = __builtin_amdgcn_readfirstlane(sh.boot[1]);
-        if (tell)
-            for (uint32_t i = (uint32_t)tid; i < gridDim.x; i += (uint32_t)kEncThreads)
-                __hip_atomic_store(&p.mode_flags[i], tag | tell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (arrival == 0u) {
-        if (wave == 0) {
-            // the control words of the NEXT launch (the host alternates between two sets) are cleared here: no memset
-            if (lane < (int)kEncGroups) { p.ctrl_next[kCtrlArrive + lane * kCtrlSlot] = 0u; p.ctrl_next[kCtrlTail + lane * kCtrlSlot] = 0u; }
-            if (lane < 4) p.ctrl_next[kCtrlVerdict + lane] = 0u;
-            scanner_loop<ALIGNED_OUT>(p, lane);
-        }
-        return;
-    }
-    const uint32_t rank = arrival - 1u;
-    ChunkRef cur = chunk_ref<PIX>(p, rank, tid);
+    if (__builtin_amdgcn_readfirstlane(sh.boot[0]) != 0u) return;
+    const uint32_t rank = blockIdx.x - 1u;          // (workgroup 0 has none)
+    ChunkRef cur = chunk_ref<PIX>(p, blockIdx.x ? rank : 0xFFFFFFFFu, tid);
     uint32_t r0a[16], r0b[16], r1a[16], r1b[16];
-    load_chunk<IN_MODE, true, PIX>(p, cur, r0a, r0b);          // in flight while the mode arrives
-    __syncthreads();   // sh.boot is reused below
+    if (blockIdx.x != 0u) load_chunk<IN_MODE, true, PIX>(p, cur, r0a, r0b);          // in flight while the mode arrives
+    lds_barrier();     // sh.boot is reused below (NOT __syncthreads: nobody waits for the pixels here)
+    if (blockIdx.x == 0u) {
+        // ---- the checker: have all G encoders announced themselves?  (or has somebody given up waiting) ----
+        if (wave == 0) {
+            uint32_t tell = 0u;
+            const uint64_t t0 = wall_clock64();
+            for (;;) {
+                uint32_t seen = 0;
+                for (uint32_t k = 1u + (uint32_t)lane; k <= G; k += 64u)
+                    seen += __hip_atomic_load(&p.arrive_flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (tag | 1u) ? 1u : 0u;
+                seen = wave_sum(seen);
+                if (seen == G) {
+                    const uint32_t verdict = (p.flags & 1u) ? 2u : 1u;
+                    uint32_t old = 0;
+                    if (lane == 0) old = atomicCAS(&p.ctrl[kCtrlVerdict], 0u, verdict);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    tell = old ? 0u : verdict;
+                    break;
+                }
+                if (__hip_atomic_load(&p.ctrl[kCtrlVerdict], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // somebody timed out
+                if (wall_clock64() - t0 > 300000000ull) { if (lane == 0) atomicOr(p.sticky, 1u); break; }                 // 3 s: give up
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) sh.boot[1] = tell;
+        }
+        __syncthreads();
+        {
+            const uint32_t tell = __builtin_amdgcn_readfirstlane(sh.boot[1]);
+            if (tell)
+                for (uint32_t i = (uint32_t)tid; i < gridDim.x; i += (uint32_t)kEncThreads)
+                    __hip_atomic_store(&p.mode_flags[i], tag | tell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) sh.boot[0] = atomicCAS(&p.ctrl[kCtrlScanner], 0u, 1u) == 0u ? 1u : 0u;
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(sh.boot[0]) != 0u) {
+            if (wave == 0) {
+                // the control words of the NEXT launch (the host alternates between two sets) are cleared here: no memset
+                if (lane < (int)kEncGroups) p.ctrl_next[kCtrlTail + lane * kCtrlSlot] = 0u;
+                if (lane < 8) p.ctrl_next[kCtrlVerdict + lane] = 0u;
+                scanner_loop<ALIGNED_OUT>(p, lane);
+            }
+            return;
+        }
+        // the role is taken (a workgroup that gave up waiting for this one): encode like the others, on tickets
+    }
     if (tid == 0) {
-        uint32_t mode = 0u, tell = 0u;
+        uint32_t mode = 0u, tell = 0u, scan = 0u;
         const uint64_t t0 = wall_clock64();
 #ifdef DBDE_DIAG
+        sh.dg[0] = t0;
         sh.dg[1] = t0;   // (first chunk's loads issued, barrier passed: the poll starts)
 #endif
         for (;;) {
-            const uint32_t f = __hip_atomic_load(&p.mode_flags[arrival], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t f = scalar_load_uncached(&p.mode_flags[blockIdx.x]);   // (not behind the pixel loads in flight)
             if ((f & ~3u) == tag && (f & 3u)) { mode = f & 3u; break; }
-            if (wall_clock64() - t0 > 2000ull) {   // 20 us: not everybody is running
-                const uint32_t old = atomicOr(&p.ctrl[kCtrlVerdict], kVerdictTimeout);
-                if (old & kVerdictTimeout) mode = 2u;                                     // somebody else timed out first (and tells)
-                else if ((old & 0xFFu) == n_grp) mode = (p.flags & 1u) ? 2u : 1u;         // everybody HAS arrived: the flag is on its way
-                else { mode = 2u; tell = 2u; }
+            if (blockIdx.x == 0u || wall_clock64() - t0 > 2000ull) {   // 20 us: not everybody is running
+                const uint32_t old = atomicCAS(&p.ctrl[kCtrlVerdict], 0u, 2u);
+                mode = old ? old : 2u;             // (a verdict that was on its way is as good as the flag)
+                if (!old) {
+                    tell = 2u;
+                    // nobody scans unless workgroup 0 runs: has it announced itself?  if not, this workgroup takes the role
+                    if (__hip_atomic_load(&p.arrive_flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (tag | 1u))
+                        scan = atomicCAS(&p.ctrl[kCtrlScanner], 0u, 1u) == 0u ? 1u : 0u;
+                }
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        sh.boot[1] = mode | (tell << 8);
+        sh.boot[1] = mode | (tell << 8) | (scan << 16);
         if (mode == 1u) {
             sh.boot[0] = rank + G;
-        } else {   // tickets: two draws -- the chunk fetched above is dropped, ids are dense in draw order from 0
-            const u64a t = atomicAdd(tickets, 2ull);
-            sh.claim[0] = (uint32_t)t;
-            sh.boot[0] = (uint32_t)t + 1u;
+        } else if (!scan) {   // tickets: the chunk fetched above is dropped, ids are dense in draw order from 0 (the second draw: below)
+            sh.claim[0] = atomicAdd(tickets, 1u);
         }
     }
-    __syncthreads();
+    lds_barrier();
     const bool static_mode = (__builtin_amdgcn_readfirstlane(sh.boot[1]) & 0xFFu) == 1u;
-    if ((__builtin_amdgcn_readfirstlane(sh.boot[1]) >> 8) != 0u)   // this workgroup settled it by time-out: everybody is told
+    if (((__builtin_amdgcn_readfirstlane(sh.boot[1]) >> 8) & 0xFFu) != 0u)   // this workgroup settled it by time-out: everybody is told
         for (uint32_t i = (uint32_t)tid; i < gridDim.x; i += (uint32_t)kEncThreads)
             __hip_atomic_store(&p.mode_flags[i], tag | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((__builtin_amdgcn_readfirstlane(sh.boot[1]) >> 16) != 0u) {          // ... and it scans, in workgroup 0's place
+        if (wave == 0) {
+            if (lane < (int)kEncGroups) p.ctrl_next[kCtrlTail + lane * kCtrlSlot] = 0u;
+            if (lane < 8) p.ctrl_next[kCtrlVerdict + lane] = 0u;
+            scanner_loop<ALIGNED_OUT>(p, lane);
+        }
+        return;
+    }
     if (!static_mode) {
         cur = chunk_ref<PIX>(p, __builtin_amdgcn_readfirstlane(sh.claim[0]), tid);
         load_chunk<IN_MODE, true, PIX>(p, cur, r0a, r0b);
+        // The second ticket is drawn BEHIND the first chunk's fetch, not with the first: two tickets drawn at once are
+        // neighbouring chunk ids, and the in-order prefix then chains the workgroups one behind the other (chunk 2 a + 1 is
+        // published only after its owner has waited for chunk 2 a's prefix, which needs 2 a - 1, ...: measured, 100 us per
+        // step).  By now the workgroups that run have all drawn their first.  (Ids stay increasing inside a workgroup: one
+        // that held a smaller id for later would wait for itself.)
+        if (tid == 0) sh.boot[0] = atomicAdd(tickets, 1u);
+        lds_barrier();
     }
     // Static strides leave the launch's tail to chance: workgroups do not run at the same speed (the first leaves 30-40 us
     // before the last on a 1-4 ms launch).  The last kTailRounds rounds of chunk ids -- everything from s_static on, the
@@ -1006,7 +1058,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
                 }
                 uint32_t tnew = 0xFFFFFFFFu;   // id of the chunk after nxt
                 if (nxt.valid) {
-                    if (!static_mode) tnew = (uint32_t)atomicAdd(tickets, 1ull);
+                    if (!static_mode) tnew = atomicAdd(tickets, 1u);
                     else if (nxt.c + G < s_static) tnew = nxt.c + G;
                     else tnew = s_static + atomicAdd(&p.ctrl[kCtrlTail + grp * kCtrlSlot], 1u) * n_grp + grp;
                 }
@@ -2483,22 +2535,31 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(DecParams p) {
         return;
     }
     // ---- odd widths (whole rows; dbde_capi.cpp sends nothing else here): tile-aligned image, shifted copy-out ----
-    // Pass 1, no branch but "has a tile": EVERY tile row goes in as one aligned 8-byte store -- the partial last tile of
-    // an image row too (what it writes behind column W lies in the 16 bytes pass 2 rewrites), rows below the image too
-    // (they lie behind the range that leaves).
+    // Every tile row goes in as one aligned 8-byte store -- rows below the image too (they lie behind the range that
+    // leaves) -- but for the partial last tile of an image row, which stores its valid bytes only: what lies behind column W
+    // belongs to the second set of stores below (round 3 let that tile write all eight bytes and put a barrier between the
+    // two sets; with disjoint targets they need none: one barrier and one LDS drain less per chunk).
     const uint32_t P = 8u * wspan + 16u;
     const uint32_t aA = 8u * rowA * P + 8u * colA, aB = 8u * rowB * P + 8u * colB;
     if (hasA) {
+        if (nA == 8u) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aA + (uint32_t)r * P, va[2 * r], va[2 * r + 1]);
+            for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aA + (uint32_t)r * P, va[2 * r], va[2 * r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) lds_store_bytes(s_px, aA + (uint32_t)r * P, ((uint64_t)va[2 * r + 1] << 32) | va[2 * r], nA);
+        }
     }
     if (hasB) {
+        if (nB == 8u) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aB + (uint32_t)r * P, vb[2 * r], vb[2 * r + 1]);
+            for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aB + (uint32_t)r * P, vb[2 * r], vb[2 * r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) lds_store_bytes(s_px, aB + (uint32_t)r * P, ((uint64_t)vb[2 * r + 1] << 32) | vb[2 * r], nB);
+        }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    // Pass 2: the first 16 bytes of every image row once more, behind the end of the image row before it (W >= 16:
+    // ... and the first 16 bytes of every image row once more, behind the end of the image row before it (W >= 16:
     // columns 0 and 1 are whole tiles; the chunk's first image row has no row before it in this chunk).
     if (hasA && colA <= 1u) {
 #pragma unroll

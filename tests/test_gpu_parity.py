@@ -597,6 +597,46 @@ def test_ticket_mode_fallback(codec, oracle, dv):
         c2.close()
 
 
+@pytest.mark.parametrize("W,H,n,concat", [(1920, 1080, 96, False), (1921, 1081, 80, True), (2048, 2048, 40, True)])
+def test_persistent_encoder_on_tickets(codec, oracle, dv, W, H, n, concat):
+    """The PERSISTENT encoder's fallback (every chunk id a ticket: what a launch falls back to when not all of its
+    workgroups are seen running), forced, on launches of several rounds: bit-exact, and not pathologically slow -- round 4
+    found a form that was correct but chained the workgroups one behind the other through the in-order prefix (two tickets
+    drawn at once are neighbouring chunk ids), ten times the static mode's time, which no correctness test noticed."""
+    import os
+    import torch
+    os.environ["DBDE_HIP_EXPERIMENT"] = "1"
+    try:
+        c2 = dv.Codec(0)
+    finally:
+        os.environ.pop("DBDE_HIP_EXPERIMENT", None)
+    try:
+        assert dv.encode_plan(W, H, n)["kernel"] == 0          # the persistent encoder (more chunks than resident workgroups)
+        imgs = codec.synth_frames("mixed", SEED, 11, n, W, H)
+        slot = 0 if concat else ((dv.max_frame_bytes(W, H) + 255) // 256) * 256
+        times = {}
+        for name, c in (("static", codec), ("tickets", c2)):
+            frames, (buf, lead, offs, sizes) = gpu_encode(c, imgs, W, H, n, first_index=11, slot_stride=slot)
+            imgs_h = imgs.cpu().numpy()
+            for f in (0, 1, n // 2, n - 1):
+                assert frames[f].tobytes() == oracle.pack_frame(11 + f, imgs_h[f], W, H).tobytes(), (name, f)
+            cap = (n - 1) * slot + dv.max_frame_bytes(W, H) if slot else int((offs[-1] + sizes[-1]).item())
+            back, _ = c.decode_frames(buf, lead, cap, offs, W, H, n)
+            c.sync()
+            assert torch.equal(back, imgs), name
+            c.timing(True)
+            c.timing_read(reset=True)
+            for _ in range(5):
+                c.encode_frames(imgs, W, H, n, buf, lead, cap if slot else n * dv.max_frame_bytes(W, H), first_index=11, offsets=offs, nbytes=sizes,
+                                slot_stride=slot)
+            c.sync()
+            times[name] = c.timing_read(reset=True)["encode"][0] / 5
+            c.timing(False)
+        assert times["tickets"] < 4.0 * times["static"], times
+    finally:
+        c2.close()
+
+
 def test_argument_and_capacity_errors(codec, dv):
     """C-ABI error behaviour: bad geometry, short buffers and null pointers are refused before
     any launch; an empty batch is a no-op."""

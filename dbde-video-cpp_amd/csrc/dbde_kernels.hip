@@ -2535,31 +2535,24 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(DecParams p) {
         return;
     }
     // ---- odd widths (whole rows; dbde_capi.cpp sends nothing else here): tile-aligned image, shifted copy-out ----
-    // Every tile row goes in as one aligned 8-byte store -- rows below the image too (they lie behind the range that
-    // leaves) -- but for the partial last tile of an image row, which stores its valid bytes only: what lies behind column W
-    // belongs to the second set of stores below (round 3 let that tile write all eight bytes and put a barrier between the
-    // two sets; with disjoint targets they need none: one barrier and one LDS drain less per chunk).
+    // Pass 1, no branch but "has a tile": EVERY tile row goes in as one aligned 8-byte store -- the partial last tile of
+    // an image row too (what it writes behind column W lies in the 16 bytes pass 2 rewrites), rows below the image too
+    // (they lie behind the range that leaves).  (Round 4 tried the partial tile with its valid bytes only, which makes the
+    // two passes' targets disjoint and saves the barrier between them: the byte stores cost the wave that holds a row end
+    // more than the barrier costs everybody -- 1921x1081 decode 1.199 -> 1.223 ms, 1366x768 1.334 -> 1.377.)
     const uint32_t P = 8u * wspan + 16u;
     const uint32_t aA = 8u * rowA * P + 8u * colA, aB = 8u * rowB * P + 8u * colB;
     if (hasA) {
-        if (nA == 8u) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aA + (uint32_t)r * P, va[2 * r], va[2 * r + 1]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++) lds_store_bytes(s_px, aA + (uint32_t)r * P, ((uint64_t)va[2 * r + 1] << 32) | va[2 * r], nA);
-        }
+        for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aA + (uint32_t)r * P, va[2 * r], va[2 * r + 1]);
     }
     if (hasB) {
-        if (nB == 8u) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aB + (uint32_t)r * P, vb[2 * r], vb[2 * r + 1]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++) lds_store_bytes(s_px, aB + (uint32_t)r * P, ((uint64_t)vb[2 * r + 1] << 32) | vb[2 * r], nB);
-        }
+        for (int r = 0; r < 8; r++) lds_store_u64_any(s_px, aB + (uint32_t)r * P, vb[2 * r], vb[2 * r + 1]);
     }
-    // ... and the first 16 bytes of every image row once more, behind the end of the image row before it (W >= 16:
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // Pass 2: the first 16 bytes of every image row once more, behind the end of the image row before it (W >= 16:
     // columns 0 and 1 are whole tiles; the chunk's first image row has no row before it in this chunk).
     if (hasA && colA <= 1u) {
 #pragma unroll

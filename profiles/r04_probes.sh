@@ -1,6 +1,7 @@
 #!/bin/bash
-# round 4, first GPU call: alignment probe (rate + FETCH_SIZE), baseline abbench lines, in-kernel diag of cfg3 / cfg4 launches
-O=gpurun_out/r04_probe1; mkdir -p $O
+# round 4: what the alignment of the encoder's pixel fetches costs (profiles/read_align_probe.hip: rate + FETCH_SIZE), baseline abbench lines,
+# the per-workgroup in-kernel timeline of persistent-encoder launches (-DDBDE_DIAG variant: profiles/variants.sh diag="-DDBDE_DIAG")
+O=gpurun_out/r04_probes; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 120 profiles/read_align_probe 1921 1081 2048 > $O/probe_1921.txt 2>&1
 timeout -k 10 120 profiles/read_align_probe 1920 1080 2048 > $O/probe_1920.txt 2>&1

@@ -107,7 +107,7 @@ struct EncParams {
     uint32_t pairs_per_wave;       // 64, or 63: dword-aligned fetches, a wave's 64th lane only feeds the 63rd (kInRaw4, dbde_kernels.hip)
     uint32_t magic_w, magic_cpf, magic_lpr;   // div_magic_of(w), (chunks_per_frame), (lanes_per_row): divisions by launch constants
     uint32_t last_frame;           // n_frames - 1: no pixel load reaches past the end of that frame
-    uint32_t flags;                // bit 0: force ticket mode (A/B measurements); bit 6 (tests): small launches, odd chunks publish nothing
+    uint32_t flags;                // bit 0: force ticket mode (A/B measurements); bit 6 (tests): small launches, odd chunks publish nothing; bit 9 (tests): workgroup 0 of a persistent launch arrives 60 us late
     uint32_t grid_blocks;          // resident workgroups of the persistent encoder
     unsigned long long *diag;      // [16] cycle counters, written only by -DDBDE_DIAG builds (profiles/variants.sh)
     uint32_t small_epoch;          // launch_encode_small: tag of THIS launch's records (1 .. 2^30 - 1; records of other launches do not match)

@@ -29,6 +29,8 @@ codec, ora = dv.Codec(0), Oracle()
 shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080), (1001, 999), (1366, 768), (641, 481), (1928, 1080),
           (720, 1280), (1440, 900), (1080, 1920), (1360, 768),   # 16-byte rows: direct 16-byte stores / staged per chunk; 8-byte rows staged
           (72, 72), (96, 96), (128, 128), (9, 600), (130, 121),   # 65 .. 272 tiles: whole frames per workgroup (encode_mid / decode_mid) and just above
+          (160, 120), (176, 144), (200, 152), (104, 100), (224, 200),   # round 4: 65 .. 640 tiles with 8-byte rows: encode_frames_kernel
+          (2999, 2001), (1923, 1083), (1935, 1080),                     # round 4: odd rows on dword-aligned fetches (kInRaw4) / last pair of 15 columns (natural)
           (1921, 1081), (1001, 999), (64, 64), (8, 8), (61, 59), (33, 31), (512, 8), (24, 16)]
 t0 = time.time()
 frames_done = 0

@@ -597,6 +597,36 @@ def test_ticket_mode_fallback(codec, oracle, dv):
         c2.close()
 
 
+@pytest.mark.parametrize("flags", [512, 513])
+def test_scanner_role_is_taken_over_when_workgroup_0_is_late(codec, oracle, dv, flags):
+    """Workgroup 0 of a persistent launch checks the arrivals, settles the mode and scans.  If it is not running (here: it
+    turns up 60 us late, $DBDE_HIP_EXPERIMENT bit 9), the encoders give up waiting for the mode after 20 us, the launch
+    falls back to tickets and the workgroup that decided so takes the scanner's role; the late workgroup 0 finds the role
+    taken and encodes on tickets like the others.  Bit-exact, no time-out."""
+    import os
+    import torch
+    os.environ["DBDE_HIP_EXPERIMENT"] = str(flags)
+    try:
+        c2 = dv.Codec(0)
+    finally:
+        os.environ.pop("DBDE_HIP_EXPERIMENT", None)
+    try:
+        for (W, H, n, concat) in ((1920, 1080, 70, False), (1921, 1081, 64, True)):
+            imgs = codec.synth_frames("mixed", SEED, 5, n, W, H)
+            slot = 0 if concat else ((dv.max_frame_bytes(W, H) + 255) // 256) * 256
+            for rep in range(3):
+                frames, (buf, lead, offs, sizes) = gpu_encode(c2, imgs, W, H, n, first_index=5, slot_stride=slot)   # (sync inside: a time-out would raise)
+            imgs_h = imgs.cpu().numpy()
+            for f in (0, 1, n // 2, n - 1):
+                assert frames[f].tobytes() == oracle.pack_frame(5 + f, imgs_h[f], W, H).tobytes(), (W, f)
+            cap = (n - 1) * slot + dv.max_frame_bytes(W, H) if slot else int((offs[-1] + sizes[-1]).item())
+            back, _ = c2.decode_frames(buf, lead, cap, offs, W, H, n)
+            c2.sync()
+            assert torch.equal(back, imgs)
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("W,H,n,concat", [(1920, 1080, 96, False), (1921, 1081, 80, True), (2048, 2048, 40, True)])
 def test_persistent_encoder_on_tickets(codec, oracle, dv, W, H, n, concat):
     """The PERSISTENT encoder's fallback (every chunk id a ticket: what a launch falls back to when not all of its
@@ -635,6 +665,44 @@ def test_persistent_encoder_on_tickets(codec, oracle, dv, W, H, n, concat):
         assert times["tickets"] < 4.0 * times["static"], times
     finally:
         c2.close()
+
+
+def test_two_persistent_encodes_at_once(oracle, dv):
+    """Two contexts on two streams, each launching persistent encodes sized for the whole device, at the same time: the
+    second launch's workgroups are not all resident while the first runs, so it cannot prove co-residency -- its workgroups
+    give up waiting for the mode after 20 us, fall back to tickets, and if its workgroup 0 is not running yet one of them
+    takes the scanner's role.  Forward progress must not depend on who got the device first; both streams bit-exact."""
+    import torch
+    W, H, n = 2048, 1024, 160                      # 32 chunks per frame: 5120 chunks, ten rounds of 511 workgroups
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    c1, c2 = dv.Codec(0, stream=s1), dv.Codec(0, stream=s2)
+    try:
+        assert dv.encode_plan(W, H, n)["kernel"] == 0
+        imgs = [c.synth_frames("mixed", SEED, 100 * k, n, W, H) for k, c in enumerate((c1, c2))]
+        bufs = [c.alloc_stream(W, H, n) for c in (c1, c2)]
+        c1.sync(); c2.sync()
+        outs = [None, None]
+        for it in range(12):
+            for k, c in enumerate((c1, c2) if it % 2 == 0 else (c2, c1)):      # who launches first alternates
+                kk = k if it % 2 == 0 else 1 - k
+                buf, lead, cap = bufs[kk]
+                outs[kk] = c.encode_frames(imgs[kk], W, H, n, buf, lead, cap, first_index=100 * kk)
+            c1.sync(); c2.sync()                       # dbde_hip_sync: a look-back time-out would surface here
+        for kk, c in enumerate((c1, c2)):
+            buf, lead, cap = bufs[kk]
+            offs, sizes = outs[kk]
+            o, s_ = offs.cpu().numpy(), sizes.cpu().numpy()
+            assert o[0] == 0 and (o[1:] == (o + s_)[:-1]).all()
+            ih = imgs[kk].cpu().numpy()
+            for f in (0, 1, n // 2, n - 1):
+                want = oracle.pack_frame(100 * kk + f, ih[f], W, H)
+                got = buf[lead + int(o[f]):lead + int(o[f] + s_[f])].cpu().numpy()
+                assert got.tobytes() == want.tobytes(), (kk, f)
+            back, _ = c.decode_frames(buf, lead, int(o[-1] + s_[-1]), offs, W, H, n)
+            c.sync()
+            assert torch.equal(back, imgs[kk]), kk
+    finally:
+        c1.close(); c2.close()
 
 
 def test_argument_and_capacity_errors(codec, dv):

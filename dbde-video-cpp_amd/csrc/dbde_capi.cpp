@@ -359,6 +359,7 @@ static EncParams enc_params(dbde_hip_ctx *ctx, const Geometry &g, int W, int H, 
     p.n_chunks = (uint32_t)n_frames * chunks_per_frame;
     p.lanes_per_row = lanes_per_row;
     p.pairs_per_wave = 64u;
+    p.seg_per_row = p.seg_q = p.seg_rem = p.magic_seg = 0u;
     p.magic_w = div_magic_of(g.w);
     p.magic_cpf = div_magic_of(chunks_per_frame);
     p.magic_lpr = div_magic_of(lanes_per_row);
@@ -421,9 +422,13 @@ static int attach_lookback(dbde_hip_ctx *ctx, EncParams &p, uint32_t n_chunks, b
 struct EncPlan {
     bool fast_in, aligned_out;
     uint32_t enc_cpf, lanes_per_row, pairs_per_wave;
+    uint32_t seg_per_row, seg_q, seg_rem;   // kInRow: segments of a tile row (0 = not taken)
     uint64_t n_chunks64;
     int kernel;            // 0 = persistent (encode_kernel), 1 = encode_small_kernel, 2 = encode_tiny_kernel, 3 = encode_mid_kernel, 4 = encode_frames_kernel
 };
+#ifndef DBDE_ROW_FILL
+#define DBDE_ROW_FILL 90
+#endif
 #ifndef DBDE_FRAMES_ENCODE_TILES
 // Frames of 65 .. this many tiles with 8-byte aligned rows encode / decode with whole frames per workgroup and staged,
 // coalesced traffic (encode_frames_kernel / decode_frames_kernel); above it the chunk kernels' 512 / 1024 tile slots are
@@ -453,6 +458,7 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
     pl.enc_cpf = (g.T + kEncChunkTiles - 1) / kEncChunkTiles;
     pl.lanes_per_row = 0;
     pl.pairs_per_wave = 64;
+    pl.seg_per_row = pl.seg_q = pl.seg_rem = 0;
     if (!pl.fast_in && W >= 16) {
         pl.lanes_per_row = (g.w + 1u) / 2u;
         // Dword-aligned fetches (kInRaw4: a 16-byte load at an odd address runs at 0.87 of the rate of one at any even
@@ -461,10 +467,28 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
         // Rows at even addresses (W and the base even) read at the full rate as they are and keep 64 pairs.
 #ifndef DBDE_NO_RAW4
         const uint32_t last_cols = (uint32_t)W - 16u * (pl.lanes_per_row - 1u);
-        if (last_cols <= 13u && ((W | (int)(images & 1u)) & 1)) pl.pairs_per_wave = 63;
+        // (32-bit offsets inside a frame: geometry() admits frames of up to 8 GiB)
+        if (last_cols <= 13u && ((W | (int)(images & 1u)) & 1) && g.pixels < (1ull << 31)) pl.pairs_per_wave = 63;
+#ifdef DBDE_ROW_ALWAYS   // A/B builds: the segment form on rows at even addresses too
+        if (last_cols <= 13u && g.pixels < (1ull << 31)) pl.pairs_per_wave = 63;
+#endif
 #endif
         const uint32_t ppc = pl.pairs_per_wave * (kEncChunkTiles / 128u);
         pl.enc_cpf = (uint32_t)(((uint64_t)g.h * pl.lanes_per_row + ppc - 1u) / ppc);
+#ifndef DBDE_NO_ROW
+        // kInRow: one wave per segment of a tile row (addresses and shifts in scalar registers) when that keeps at least
+        // DBDE_ROW_FILL percent of the lanes busy -- 1921 wide: 121 pairs = 61 + 60 of 128 lanes
+        if (pl.pairs_per_wave == 63u) {
+            const uint32_t nseg = (pl.lanes_per_row + 62u) / 63u;
+            if (100u * pl.lanes_per_row >= (unsigned)DBDE_ROW_FILL * 64u * nseg && pl.lanes_per_row / nseg >= 2u) {
+                pl.seg_per_row = nseg;
+                pl.seg_q = pl.lanes_per_row / nseg;
+                pl.seg_rem = pl.lanes_per_row % nseg;
+                const uint32_t spc = kEncChunkTiles / 128u;   // segments (waves) per chunk
+                pl.enc_cpf = (uint32_t)(((uint64_t)g.h * nseg + spc - 1u) / spc);
+            }
+        }
+#endif
     }
     pl.n_chunks64 = (uint64_t)n_frames * pl.enc_cpf;
     pl.aligned_out = ((out & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
@@ -516,6 +540,10 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.indices = d_indices;
     p.elapsed_ns = d_elapsed_ns;
     p.pairs_per_wave = pl.pairs_per_wave;
+    p.seg_per_row = pl.seg_per_row;
+    p.seg_q = pl.seg_q;
+    p.seg_rem = pl.seg_rem;
+    p.magic_seg = pl.seg_per_row ? div_magic_of(pl.seg_per_row) : 0u;
 
     if (pl.kernel == 2) {   // tiny frames in slots: several frames per wave, nothing shared (encode_tiny_kernel)
         span_begin(ctx, 0);
@@ -869,11 +897,11 @@ int dbde_hip_encode_plan(int W, int H, int n_frames, uint64_t image_address, uin
     const EncPlan pl = plan_encode(g, W, n_frames, (uintptr_t)image_address, (uintptr_t)out_address, slot_stride, (uint32_t)resident_workgroups);
     memset(plan, 0, sizeof *plan);
     plan->kernel = pl.kernel;
-    plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? (pl.pairs_per_wave == 63u ? 3 : 1) : 2);
+    plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? (pl.seg_per_row ? 4 : pl.pairs_per_wave == 63u ? 3 : 1) : 2);
     plan->aligned_out = pl.aligned_out ? 1 : 0;
     plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u)));
     plan->chunks_per_frame = pl.kernel >= 2 ? 0u : pl.enc_cpf;
-    plan->chunk_tiles = pl.kernel >= 2 ? 0u : (pl.lanes_per_row ? 2u * pl.pairs_per_wave * (kEncChunkTiles / 128u) : kEncChunkTiles);
+    plan->chunk_tiles = pl.kernel >= 2 ? 0u : (pl.seg_per_row ? 2u * (pl.seg_q + (pl.seg_rem ? 1u : 0u)) * (kEncChunkTiles / 128u) : pl.lanes_per_row ? 2u * pl.pairs_per_wave * (kEncChunkTiles / 128u) : kEncChunkTiles);
     plan->n_chunks = pl.kernel >= 2 ? 0ull : pl.n_chunks64;
     return DBDE_HIP_OK;
 }

@@ -106,6 +106,9 @@ struct EncParams {
     uint32_t lanes_per_row;
     uint32_t pairs_per_wave;       // 64, or 63: dword-aligned fetches, a wave's 64th lane only feeds the 63rd (kInRaw4, dbde_kernels.hip)
     uint32_t magic_w, magic_cpf, magic_lpr;   // div_magic_of(w), (chunks_per_frame), (lanes_per_row): divisions by launch constants
+    // kInRow (dbde_kernels.hip): a tile row is cut into seg_per_row segments of seg_q or seg_q + 1 pairs (the first seg_rem
+    // of them), one wave each; 0 = lanes dealt to pairs linearly
+    uint32_t seg_per_row, seg_q, seg_rem, magic_seg;
     uint32_t last_frame;           // n_frames - 1: no pixel load reaches past the end of that frame
     uint32_t flags;                // bit 0: force ticket mode (A/B measurements); bit 6 (tests): small launches, odd chunks publish nothing; bit 9 (tests): workgroup 0 of a persistent launch arrives 60 us late
     uint32_t grid_blocks;          // resident workgroups of the persistent encoder

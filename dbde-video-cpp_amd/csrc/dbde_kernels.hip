@@ -442,17 +442,22 @@ struct ChunkRef {
     uint32_t c, f, cf, t0;     // t0: stream index of the lane's first tile
     uint32_t ty, tx;           // its tile row and column
     bool valid, hasA, hasB;
-    bool loads;                // the lane fetches pixels at (ty, tx): hasA, or (kInRaw4) the wave's 64th lane, which only feeds lane 62
+    bool loads;                // the lane fetches pixels at (ty, tx): hasA, or (kInRaw4, kInRow) the lane behind the wave's pairs, which only feeds the last of them
+    uint32_t seg_j0;           // kInRow (wave-uniform): first pair of the wave's segment of tile row ty
+    bool seg_last;             // ... and whether the segment ends the tile row
 };
 
 template <int PIX = 1>
 __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, int tidw) {
     ChunkRef k;
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);   // wave-uniform at every call site: frame, chunk-in-frame (and kInRow's tile row) in scalar registers
     k.c = c;
     k.valid = c < p.n_chunks;
     uint32_t cf = 0;
     k.f = k.valid ? div_magic(c, p.chunks_per_frame, p.magic_cpf, cf) : 0u;
     k.cf = k.valid ? cf : 0u;
+    k.seg_j0 = 0u;
+    k.seg_last = false;
     if (PIX == 2) {                         // DBDE16: ONE tile per lane (a tile row is 16 bytes), 512 consecutive tiles
         k.t0 = k.cf * (kEncChunkTiles / 2u) + (uint32_t)tidw;
         k.hasA = k.hasB = k.valid && k.t0 < p.T;
@@ -464,6 +469,22 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
         k.hasB = k.valid && k.t0 + 1u < p.T;
         k.ty = div_magic(k.t0, p.w, p.magic_w, k.tx);
         k.loads = k.hasA;
+    } else if (p.seg_per_row != 0u) {       // kInRow: a wave = one segment of ONE tile row; everything but the lane's column is scalar
+        const uint32_t lane = (uint32_t)tidw & 63u;
+        const uint32_t seg = k.cf * (uint32_t)kEncWaves + (uint32_t)__builtin_amdgcn_readfirstlane(tidw >> 6);
+        uint32_t sidx;
+        const uint32_t ty = div_magic(seg, p.seg_per_row, p.magic_seg, sidx);
+        const uint32_t len = p.seg_q + (sidx < p.seg_rem ? 1u : 0u);
+        k.seg_j0 = sidx * p.seg_q + (sidx < p.seg_rem ? sidx : p.seg_rem);
+        k.seg_last = sidx + 1u == p.seg_per_row;
+        const uint32_t j = k.seg_j0 + lane;
+        const bool row = k.valid && ty < p.h;
+        k.ty = ty;
+        k.tx = 2u * j;
+        k.t0 = ty * p.w + k.tx;
+        k.hasA = row && lane < len;
+        k.hasB = k.hasA && k.tx + 1u < p.w;
+        k.loads = row && lane <= len && j < p.lanes_per_row;   // (lane `len`: the next segment's first pair, for the sake of lane len - 1)
     } else {                                // the lane's pair: tile row = pair / lanes_per_row
         // pairs_per_wave = 64: 512 consecutive pairs per chunk.  63 (kInRaw4): a wave OWNS 63 consecutive pairs and its
         // 64th lane fetches the pair after them -- the first pair of the next wave -- for the sake of lane 62 alone
@@ -503,7 +524,41 @@ __device__ __forceinline__ ChunkRef chunk_ref(const EncParams &p, uint32_t c, in
 //             Image rows whose fetches must not move -- the batch's last image row, whose last fetch is moved LEFT to
 //             end with the buffer, and a first row that would start in front of it -- are fetched as kInRaw does, by
 //             the whole wave (a wave-uniform vote, taken again when the registers are consumed).
-constexpr int kInFast = 0, kInRaw = 1, kInBytes = 2, kInRaw4 = 3;
+//   kInRow  : kInRaw4 with the lanes dealt differently: a wave works on one SEGMENT of one tile row (chunk_ref) -- the
+//             tile row is cut into ceil(pairs / 63) nearly equal segments -- so the image row, the segment's start and the
+//             shift b are the same for all its lanes: they live in scalar registers, a fetch is `scalar base + 16 * lane`
+//             (no vector arithmetic per image row), b needs no per-lane work when the registers are consumed, and "does this
+//             wave hold a row end / the batch's last fetch" are scalar tests instead of votes.  Idle lanes are what it
+//             costs: the host takes it when the segments fill at least 90 % of their waves (1921 wide: 121 pairs = 61 + 60
+//             of 128 lanes) and kInRaw4's linear deal otherwise.
+constexpr int kInFast = 0, kInRaw = 1, kInBytes = 2, kInRaw4 = 3, kInRow = 4;
+
+// kInRow: the wave's place in fetch row r -- byte offset in the frame of its segment's start, and by how many bytes (0..3) the row's
+// fetches are moved down to a dword boundary.  All scalar.  Rows that must stay where they are: the batch's last image row
+// in the wave that holds its moved-left last fetch (`pinned`), and the batch's very first fetch when it would start in
+// front of the caller's buffer.
+struct RowSeg {
+    uint32_t ty, j0, base_lo;
+    bool pin, first;
+    __device__ __forceinline__ uint32_t row(const EncParams &p, int r, uint32_t &off, bool &pinned) const {
+        uint32_t yy = 8u * ty + (uint32_t)r;
+        yy = yy < (uint32_t)p.H ? yy : (uint32_t)p.H - 1u;       // rows below the image repeat its last row
+        off = yy * (uint32_t)p.W + 16u * j0;
+        pinned = pin && yy == (uint32_t)p.H - 1u;
+        return (pinned || (first && r == 0)) ? 0u : (base_lo + off) & 3u;
+    }
+};
+__device__ __forceinline__ RowSeg row_seg(const EncParams &p, const ChunkRef &k, const uint8_t *img) {
+    RowSeg s;
+    // (wave-uniform by construction; said again where the compiler has lost track of it across the pipeline's loop)
+    const bool row = k.valid && k.ty < p.h;                      // (a wave behind the frame's last tile row fetches like its first)
+    s.ty = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row ? k.ty : 0u));
+    s.j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row ? k.seg_j0 : 0u));
+    s.base_lo = (uint32_t)reinterpret_cast<uintptr_t>(img);
+    s.pin = __builtin_amdgcn_readfirstlane((int)(row && k.seg_last && k.f == p.last_frame)) != 0;
+    s.first = k.f == 0u && s.ty == 0u && s.j0 == 0u && (s.base_lo & 3u) != 0u;
+    return s;
+}
 
 // kInRaw4: which of a chunk's eight fetch rows must stay where they are, for the whole wave (bit r: row r) -- the batch's
 // last image row when the wave holds its moved-left last fetch, and the batch's very first fetch when moving it down
@@ -522,7 +577,7 @@ __device__ __forceinline__ uint32_t raw4_natural_rows(const EncParams &p, const 
 }
 
 // The eight fetch rows of a kInRaw4 lane: where each fetch would naturally start (byte offset in the frame; a frame has
-// fewer than 2^30 pixels, so 32 bits and ONE multiplication per chunk) and by how many bytes (0..3) it is moved down to a
+// fewer than 2^31 pixels when this form is taken (EncPlan), so 32 bits and ONE multiplication per chunk) and by how many bytes (0..3) it is moved down to a
 // dword boundary.  Worked out twice, when the loads are issued and when their registers are consumed, from the same
 // inputs: the kernel sits at its VGPR limit and carries nothing from one to the other.
 struct Raw4Rows {
@@ -558,7 +613,27 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
         for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
     }
     const uint8_t *img = p.images + (size_t)k.f * p.frame_pixels;
-    if (IN_MODE == kInFast || IN_MODE == kInRaw || IN_MODE == kInRaw4) {
+    if (IN_MODE == kInRow) {
+        // scalar base + one vector offset that is the same in all eight rows: 16 * lane -- but 0 for lanes that fetch nothing
+        // (they read the segment's first bytes), and where the batch's last fetch must END with the buffer in a pinned row
+        const RowSeg sg = row_seg(p, k, img);
+        const uint32_t lane_off = k.loads ? 8u * k.tx - 16u * sg.j0 : 0u;
+        const bool is_end = k.loads && (k.tx >> 1) + 1u == p.lanes_per_row;
+        const uint32_t end_off = is_end ? (uint32_t)p.W - 16u - 16u * sg.j0 : lane_off;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t off;
+            bool pinned;
+            const uint32_t b = sg.row(p, r, off, pinned);
+            const uint8_t *sbase = img + (ptrdiff_t)(int32_t)(off - b);     // (signed: up to 3 bytes in front of the frame)
+            const uint8_t *src = sbase + (size_t)(pinned ? end_off : lane_off);
+            typedef u32x4_t __attribute__((aligned(1))) u32x4_unaligned;
+            const u32x4_t q = DBDE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(src))
+                                      : *reinterpret_cast<const u32x4_unaligned *>(src);
+            va[2 * r] = q[0]; va[2 * r + 1] = q[1];
+            vb[2 * r] = q[2]; vb[2 * r + 1] = q[3];
+        }
+    } else if (IN_MODE == kInFast || IN_MODE == kInRaw || IN_MODE == kInRaw4) {
         constexpr bool RAW = IN_MODE == kInRaw || IN_MODE == kInRaw4;
         // No branch around the loads: a lane without tiles reads tile 0 of frame 0 and nobody looks
         // at the result.  With a conditional issue the compiler cannot know how many loads are in
@@ -611,8 +686,23 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
 template <int IN_MODE>
 __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                                    uint32_t (&vb)[16]) {
-    if (IN_MODE != kInRaw && IN_MODE != kInRaw4) return;
+    if (IN_MODE != kInRaw && IN_MODE != kInRaw4 && IN_MODE != kInRow) return;
     const uint32_t x0 = 8u * k.tx, W = (uint32_t)p.W;
+    if (IN_MODE == kInRow) {   // as kInRaw4 below, with the shift of each row in a scalar register
+        const RowSeg sg = row_seg(p, k, p.images + (size_t)k.f * p.frame_pixels);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t off;
+            bool pinned;
+            const uint32_t b = sg.row(p, r, off, pinned);
+            const uint32_t t0 = va[2 * r], t1 = va[2 * r + 1], t2 = vb[2 * r], t3 = vb[2 * r + 1];
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t0, 0x130, 0xF, 0xF, false);   // wave_shl:1
+            va[2 * r] = __builtin_amdgcn_alignbyte(t1, t0, b);
+            va[2 * r + 1] = __builtin_amdgcn_alignbyte(t2, t1, b);
+            vb[2 * r] = __builtin_amdgcn_alignbyte(t3, t2, b);
+            vb[2 * r + 1] = __builtin_amdgcn_alignbyte(n0, t3, b);
+        }
+    }
     if (IN_MODE == kInRaw4) {
         // every fetch had been moved down to a dword boundary (load_chunk): the lane's 16 bytes are bytes b .. b + 15 of its
         // own four dwords followed by the next lane's first one (wave_shl:1 -- lane 63 receives nothing and owns no tile)
@@ -1083,7 +1173,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
             } else {
                 // the any-geometry forms sit at the register limit: the lane's place in the chunk is worked out again here
                 // (ten VALU) instead of being carried from the step that issued the loads
-                if (IN_MODE == kInRaw4 || IN_MODE == kInRaw) cur = chunk_ref<PIX>(p, cur.c, tid);
+                if (IN_MODE == kInRaw4 || IN_MODE == kInRaw || IN_MODE == kInRow) cur = chunk_ref<PIX>(p, cur.c, tid);
                 load_fixup_generic<IN_MODE>(p, cur, ca, cb);
                 tile_minmax(ca, mnA, mxA);
                 tile_minmax(cb, mnB, mxB);
@@ -1249,7 +1339,7 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
 }
 
 static int in_mode_of(const EncParams &p, bool fast_in) {
-    return fast_in ? kInFast : (p.lanes_per_row ? (p.pairs_per_wave == 63u ? kInRaw4 : kInRaw) : kInBytes);
+    return fast_in ? kInFast : (p.lanes_per_row ? (p.seg_per_row ? kInRow : p.pairs_per_wave == 63u ? kInRaw4 : kInRaw) : kInBytes);
 }
 
 // DBDE16 through the same persistent kernel (PIX = 2): W % 8 == 0 and a 16-byte aligned base, 512 tiles per chunk,
@@ -1274,6 +1364,8 @@ hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hip
         case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInBytes, true>), grid, block, 0, s, p); break;
         case kInRaw4 * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInRaw4, true>), grid, block, 0, s, p); break;
         case kInRaw4 * 2 + 0: hipLaunchKernelGGL((encode_kernel<kInRaw4, false>), grid, block, 0, s, p); break;
+        case kInRow * 2 + 1: hipLaunchKernelGGL((encode_kernel<kInRow, true>), grid, block, 0, s, p); break;
+        case kInRow * 2 + 0: hipLaunchKernelGGL((encode_kernel<kInRow, false>), grid, block, 0, s, p); break;
         default: hipLaunchKernelGGL((encode_kernel<kInBytes, false>), grid, block, 0, s, p); break;
     }
     return hipGetLastError();
@@ -1429,6 +1521,8 @@ hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_ou
         case kInBytes * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInBytes, true>), grid, block, 0, s, p); break;
         case kInRaw4 * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInRaw4, true>), grid, block, 0, s, p); break;
         case kInRaw4 * 2 + 0: hipLaunchKernelGGL((encode_small_kernel<kInRaw4, false>), grid, block, 0, s, p); break;
+        case kInRow * 2 + 1: hipLaunchKernelGGL((encode_small_kernel<kInRow, true>), grid, block, 0, s, p); break;
+        case kInRow * 2 + 0: hipLaunchKernelGGL((encode_small_kernel<kInRow, false>), grid, block, 0, s, p); break;
         default: hipLaunchKernelGGL((encode_small_kernel<kInBytes, false>), grid, block, 0, s, p); break;
     }
     return hipGetLastError();

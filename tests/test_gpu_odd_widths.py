@@ -111,3 +111,45 @@ def test_config4_against_reference_sha(dv, golden, mode):
     codec.sync()
     assert torch.equal(back, imgs)
     codec.close()
+
+
+@pytest.mark.parametrize("W,H,n", [
+    # one wave per segment of a tile row (input_mode 4): 121 pairs = 61 + 60, 63 = one wave, 188 = 63 + 63 + 62,
+    # and an even width that takes the form only at an odd base
+    (1921, 17, 3), (1921, 17, 700), (1001, 25, 3), (1001, 25, 600), (2999, 17, 2), (2999, 9, 560), (1928, 16, 3), (1928, 9, 600),
+    (1921, 1081, 2),
+    # pairs dealt linearly, 63 per wave (input_mode 3): segments would leave the waves half empty
+    (1081, 33, 3), (1081, 9, 900), (1009, 9, 3), (4093, 9, 2), (4093, 9, 300),
+    # fifteen columns in the last pair: fetched where they lie (input_mode 1)
+    (1935, 17, 3)])
+def test_encoder_fetch_forms_at_every_image_base(rows_codec, oracle, dv, W, H, n):
+    """The any-geometry encoder moves its fetches down to dword boundaries when image rows start at odd addresses, in one
+    of two lane arrangements (dbde_hip_encode_plan: input_mode 3 / 4).  Images at every base address mod 4 (and a few mod
+    128), in a buffer that ENDS with the last image (the batch's last fetch is pinned to end there), few frames (one
+    workgroup per chunk) and enough for the persistent kernel: every frame byte for byte against the oracle."""
+    import torch
+    codec = rows_codec
+    rng = np.random.default_rng(W * 7 + H * 3 + n)
+    few = min(n, 4)
+    imgs_h = codec.synth_frames("mixed", SEED, 11, n, W, H).cpu().numpy()
+    imgs_h[-1, -1, -16:] = rng.integers(0, 256, 16, dtype=np.uint8)          # the pinned fetch's bytes matter
+    imgs_h[0, 0, :16] = rng.integers(0, 256, 16, dtype=np.uint8)
+    check = sorted(set(list(range(few)) + list(range(n - few, n)) + [int(x) for x in rng.integers(0, n, 8)]))
+    want = {f: oracle.pack_frame(40 + f, imgs_h[f], W, H) for f in check}
+    slot = ((codec.L.dbde_hip_max_frame_bytes(W, H) + 255) // 256) * 256
+    modes = set()
+    for base in (0, 1, 2, 3, 5, 127):
+        canvas = torch.full((256 + base + n * W * H,), 0xEE, dtype=torch.uint8, device="cuda")
+        view = canvas[256 + base:].view(n, H, W)
+        view.copy_(torch.from_numpy(imgs_h))
+        modes.add(dv.encode_plan(W, H, n, image_address=view.data_ptr(), slot_stride=slot)["input_mode"])
+        buf, lead, cap = codec.alloc_stream(W, H, n, slot_stride=slot)
+        offs, sizes = codec.encode_frames(view, W, H, n, buf, lead, cap, first_index=40, slot_stride=slot)
+        codec.sync()
+        s = sizes.cpu().numpy()
+        for f in check:
+            got = buf[lead + f * slot: lead + f * slot + int(s[f])].cpu().numpy()
+            assert got.tobytes() == want[f].tobytes(), (W, H, n, base, f)
+        assert (canvas[:256 + base] == 0xEE).all()
+    expect = {1921: {4}, 1001: {4}, 2999: {4}, 1928: {1, 4}, 1081: {3}, 1009: {3}, 4093: {3}, 1935: {1}}[W]
+    assert modes == expect, modes

@@ -76,6 +76,8 @@ PERSISTENT = ["_ZN4dbde13encode_kernelILi0ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde
               "_ZN4dbde13encode_kernelILi1ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi1ELb0ELi1EEEvNS_9EncParamsE",
               # any geometry, dword-aligned fetches (round 4)
               "_ZN4dbde13encode_kernelILi3ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi3ELb0ELi1EEEvNS_9EncParamsE",
+              # ... one wave per segment of a tile row (round 4)
+              "_ZN4dbde13encode_kernelILi4ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi4ELb0ELi1EEEvNS_9EncParamsE",
               # DBDE16 through the same kernel (PIX = 2: one 16-bit tile per lane, the same eight 16-byte loads per step)
               "_ZN4dbde13encode_kernelILi0ELb1ELi2EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0ELi2EEEvNS_9EncParamsE"]
 

@@ -32,11 +32,15 @@ def test_baseline_configs():
     # configs[3]: 1921x1081 -- any-geometry encoder, staged decode on chunks of two whole tile rows (2 x 241 tiles)
     e = dv.encode_plan(1921, 1081, 2048, slot_stride=2168320)
     # (round 4: dword-aligned fetches -- input mode 3 -- a wave owns 63 tile pairs: 8 x 63 x 2 tiles per chunk, 136 x 121 pairs)
-    assert (e["kernel"], e["input_mode"], e["aligned_out"], e["chunk_tiles"], e["chunks_per_frame"]) == (PERSISTENT, 3, 1, 1008, 33)
+    assert (e["kernel"], e["input_mode"], e["aligned_out"], e["chunk_tiles"], e["chunks_per_frame"]) == (PERSISTENT, 4, 1, 976, 34)   # 121 pairs per tile row = segments of 61 + 60, one wave each
     # rows that are dword aligned already, or whose last pair holds more than 13 columns, keep natural-position fetches
     assert dv.encode_plan(1928, 1080, 2048)["input_mode"] == 1      # even addresses read at the full rate as they are
     assert dv.encode_plan(1366, 768, 2048)["input_mode"] == 1
-    assert dv.encode_plan(1928, 1080, 2048, image_address=1)["input_mode"] == 3
+    assert dv.encode_plan(1928, 1080, 2048, image_address=1)["input_mode"] == 4
+    e = dv.encode_plan(1081, 1921, 2048)                           # 68 pairs per tile row would half fill two waves: dealt linearly
+    assert (e["input_mode"], e["chunk_tiles"]) == (3, 1008)
+    e = dv.encode_plan(1001, 1001, 2048)                           # 63 pairs: one full wave per tile row
+    assert (e["input_mode"], e["chunk_tiles"], e["chunks_per_frame"]) == (4, 1008, 16)
     assert dv.encode_plan(1935, 1080, 2048)["input_mode"] == 1      # last pair: 15 columns
     d = dv.decode_plan(1921, 1081, 2048)
     assert (d["image_mode"], d["threads"], d["chunk_tiles"], d["chunks_per_frame"]) == (STAGED, 256, 482, 68)

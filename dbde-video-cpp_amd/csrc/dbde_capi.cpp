@@ -958,7 +958,11 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
         const uint32_t cpf2 = (g.T + kEncChunkTiles / 2u - 1u) / (kEncChunkTiles / 2u);
         const uint64_t n_chunks64 = (uint64_t)n_frames * cpf2;
         const bool fits = 16ull * g.T < (1ull << 30) && (slot_stride != 0 || (uint64_t)n_frames * 16ull * g.T < (1ull << 32));
-        if (W % 8 == 0 && (reinterpret_cast<uintptr_t>(d_images) & 15u) == 0 && fits && n_chunks64 >= ctx->enc_grid &&
+        const bool fast_in = W % 8 == 0 && (reinterpret_cast<uintptr_t>(d_images) & 15u) == 0;
+        // (any other geometry from 8 pixels across on: the same kernel with its fetches where they lie -- U16 rows always
+        // start at even addresses, which read at the full rate; a frame's bytes stay below 2^32 for its 32-bit offsets)
+        const bool raw_in = !fast_in && W >= 8 && 2ull * g.pixels < (1ull << 32) && (reinterpret_cast<uintptr_t>(d_images) & 1u) == 0;
+        if ((fast_in || raw_in) && fits && n_chunks64 >= ctx->enc_grid &&
             n_chunks64 < (1ull << 31) && !(ctx->exp_flags & 32u)) {
             EncParams q = enc_params(ctx, g, W, H, n_frames, 2u, cpf2, 0u, reinterpret_cast<const uint8_t *>(d_images), d_out,
                                      slot_stride, first_index, d_frame_offsets, d_frame_bytes);
@@ -966,7 +970,7 @@ int dbde16_hip_encode_frames(dbde_hip_ctx *ctx, const uint16_t *d_images, int W,
             span_begin(ctx, 0);
             int rc = attach_lookback(ctx, q, q.n_chunks, false);
             if (rc) return rc;
-            HIP_TRY(ctx, launch_encode16_fast(q, aligned_out, ctx->stream));
+            HIP_TRY(ctx, launch_encode16_fast(q, fast_in, aligned_out, ctx->stream));
             span_end(ctx);
             return DBDE_HIP_OK;
         }

@@ -161,7 +161,7 @@ struct FrameResultDev {             // layout of dbde_hip_frame_result
 
 hipError_t launch_encode(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 // DBDE16 (U16 pixels, W % 8 == 0, 16-byte aligned base) through the persistent encoder: 512 tiles per chunk, frame_pixels in bytes
-hipError_t launch_encode16_fast(const EncParams &p, bool aligned_out, hipStream_t s);
+hipError_t launch_encode16_fast(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s);
 // Launches with at most as many chunks as the device holds workgroups: one workgroup per chunk (chunk id = workgroup id),
 // no scanner; records are tagged with EncParams::small_epoch and never cleared (the workspace only has to have been
 // zeroed once since it was allocated).

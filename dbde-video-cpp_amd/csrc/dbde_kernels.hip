@@ -607,7 +607,7 @@ __device__ __forceinline__ Raw4Rows raw4_rows(const EncParams &p, const ChunkRef
 template <int IN_MODE, bool ZERO = true, int PIX = 1>
 __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                            uint32_t (&vb)[16]) {
-    static_assert(PIX == 1 || IN_MODE == kInFast, "DBDE16 has the aligned input path only");
+    static_assert(PIX == 1 || IN_MODE == kInFast || IN_MODE == kInRaw, "DBDE16: aligned rows, or fetches where they lie (U16 rows always start at even addresses)");
     if (ZERO) {   // (callers that never read registers of tile-less lanes skip this)
 #pragma unroll
         for (int i = 0; i < 16; i++) { va[i] = 0; vb[i] = 0; }
@@ -643,7 +643,8 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
         // kInRaw: the 16 bytes of a row's last lane run into the next image row -- harmless, those bytes are replaced by
         // the constant padding (load_fixup_generic) -- except in the last image row of the batch, where they would pass
         // the end of the caller's buffer: there, and only there, the fetch is moved left to END at the row's last pixel
-        const bool at_end = RAW && k.f == p.last_frame && x0 + 16u > (uint32_t)p.W;
+        const uint32_t row_bytes = (uint32_t)(PIX * p.W);
+        const bool at_end = RAW && k.f == p.last_frame && x0 + 16u > row_bytes;
         Raw4Rows rw;
         if (IN_MODE == kInRaw4) rw = raw4_rows(p, k, img, ty, tx, at_end);
 #pragma unroll
@@ -657,7 +658,7 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
             } else {
                 int yy = 8 * (int)ty + r;
                 yy = yy < p.H ? yy : p.H - 1;   // bottom padding = repeat the last row
-                const uint32_t xr = at_end && yy == p.H - 1 ? (uint32_t)p.W - 16u : x0;
+                const uint32_t xr = at_end && yy == p.H - 1 ? row_bytes - 16u : x0;
                 src = img + (size_t)yy * (size_t)(PIX * p.W) + xr;
             }
             u32x4_t q;
@@ -683,11 +684,12 @@ __device__ __forceinline__ void load_chunk(const EncParams &p, const ChunkRef &k
 //   * the constant padding of a tile row's last tile(s): the last valid pixel repeated (dbde_util.cpp:116-128) --
 //     branch-free on the two dwords of a tile row, per-lane masks (valid columns rm == 8 changes nothing);
 //   * in the last image row of the batch the fetch had been moved left (load_chunk): shifted back first.
-template <int IN_MODE>
+template <int IN_MODE, int PIX = 1>
 __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const ChunkRef &k, uint32_t (&va)[16],
                                                    uint32_t (&vb)[16]) {
     if (IN_MODE != kInRaw && IN_MODE != kInRaw4 && IN_MODE != kInRow) return;
-    const uint32_t x0 = 8u * k.tx, W = (uint32_t)p.W;
+    // (PIX == 2, DBDE16: ONE tile of 16 bytes per lane and row -- W below counts the BYTES of an image row)
+    const uint32_t x0 = (PIX == 2 ? 16u : 8u) * k.tx, W = (uint32_t)(PIX * p.W);
     if (IN_MODE == kInRow) {   // as kInRaw4 below, with the shift of each row in a scalar register
         const RowSeg sg = row_seg(p, k, p.images + (size_t)k.f * p.frame_pixels);
 #pragma unroll
@@ -721,7 +723,7 @@ __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const Chu
         }
     }
     // the lane that holds a tile row's last tile: tile A when w is odd (the pair's second tile does not exist), else tile B
-    const bool last_lane = k.hasA && k.tx + 2u >= p.w;
+    const bool last_lane = k.hasA && k.tx + (PIX == 2 ? 1u : 2u) >= p.w;
     const bool at_end = last_lane && k.f == p.last_frame && x0 + 16u > W;
     if (__any((int)at_end)) {   // (once per launch, in the workgroup that holds the batch's last tile row)
         const uint32_t sh = x0 + 16u - W;            // bytes the fetch was moved left: 1..15
@@ -742,6 +744,26 @@ __device__ __forceinline__ void load_fixup_generic(const EncParams &p, const Chu
     // every tile row, and it is the lane's tile A or B by the parity of w: the masks are launch constants (scalar), one
     // tile is patched, not two (round 3 worked out per-lane masks for both tiles: twice the work in every wave that holds
     // a row end -- more than half of them at 241 tiles across).
+    if (PIX == 2) {   // the row's last tile: rm valid U16 columns, the last of them repeated (oracle/dbde16_oracle.c)
+        const uint32_t rm = (uint32_t)p.W - 8u * (p.w - 1u);          // 1..8
+        if (rm == 8u || !__any((int)last_lane)) return;
+        const uint32_t src = (rm - 1u) >> 1, hi_half = (rm - 1u) & 1u;    // dword and half of the last valid pixel (launch constants)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t d[4] = {va[2 * r], va[2 * r + 1], vb[2 * r], vb[2 * r + 1]};
+            const uint32_t sv = src == 0u ? d[0] : src == 1u ? d[1] : src == 2u ? d[2] : d[3];
+            const uint32_t f = ((hi_half ? sv >> 16 : sv) & 0xFFFFu) * 0x00010001u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // columns 2j, 2j + 1 of the tile row: both valid, the first only, neither
+                const uint32_t keep = rm >= 2u * (uint32_t)j + 2u ? 0xFFFFFFFFu : rm == 2u * (uint32_t)j + 1u ? 0x0000FFFFu : 0u;
+                const uint32_t kk = last_lane ? keep : 0xFFFFFFFFu;
+                d[j] = (d[j] & kk) | (f & ~kk);
+            }
+            va[2 * r] = d[0]; va[2 * r + 1] = d[1]; vb[2 * r] = d[2]; vb[2 * r + 1] = d[3];
+        }
+        return;
+    }
     const uint32_t rm = W - 8u * (p.w - 1u);          // 1..8
     if (rm == 8u || !__any((int)last_lane)) return;
     const uint32_t m0 = rm >= 4u ? 0xFFFFFFFFu : (1u << (8u * rm)) - 1u;                 // valid bytes of the low dword
@@ -1167,6 +1189,10 @@ __global__ __launch_bounds__(kEncThreads, 4) void encode_kernel(EncParams p) {
         uint32_t mnA, mxA, mnB, mxB, dA, dB, incl, wtot;
         auto statistics = [&]() __attribute__((always_inline)) {
             if (PIX == 2) {   // one 16-bit tile per lane: "A" is the tile, "B" stays empty
+                if (IN_MODE == kInRaw) {
+                    cur = chunk_ref<PIX>(p, cur.c, tid);
+                    load_fixup_generic<IN_MODE, PIX>(p, cur, ca, cb);
+                }
                 tile_minmax16(ca, cb, mnA, mxA);
                 dA = cur.hasA ? depth_of_range(mxA - mnA) : 0u;
                 mnB = 0u; mxB = 0u; dB = 0u;
@@ -1344,10 +1370,13 @@ static int in_mode_of(const EncParams &p, bool fast_in) {
 
 // DBDE16 through the same persistent kernel (PIX = 2): W % 8 == 0 and a 16-byte aligned base, 512 tiles per chunk,
 // EncParams::frame_pixels in BYTES.  Other geometries and small launches stay with dbde16_kernels.hip.
-hipError_t launch_encode16_fast(const EncParams &p, bool aligned_out, hipStream_t s) {
+hipError_t launch_encode16_fast(const EncParams &p, bool fast_in, bool aligned_out, hipStream_t s) {
     dim3 block(kEncThreads);
     dim3 grid(p.n_chunks + 1u < p.grid_blocks ? p.n_chunks + 1u : p.grid_blocks);
-    if (aligned_out) hipLaunchKernelGGL((encode_kernel<kInFast, true, 2>), grid, block, 0, s, p);
+    if (!fast_in) {   // any width from 8 pixels on, any (U16-aligned) base: fetches where they lie
+        if (aligned_out) hipLaunchKernelGGL((encode_kernel<kInRaw, true, 2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((encode_kernel<kInRaw, false, 2>), grid, block, 0, s, p);
+    } else if (aligned_out) hipLaunchKernelGGL((encode_kernel<kInFast, true, 2>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((encode_kernel<kInFast, false, 2>), grid, block, 0, s, p);
     return hipGetLastError();
 }

@@ -9,6 +9,9 @@ W, H, n = 4096, 3072, 128
 SLOTS = False
 if len(sys.argv) > 1 and sys.argv[1] == "frames":   # many small frames, one slot each
     W, H, n, SLOTS = 1024, 768, 2048, True
+CROP = None
+if "odd" in sys.argv:    # a width that is no multiple of 8 pixels: the any-geometry form of the persistent encoder (round 4)
+    CROP = (4091, 3070)
 codec = dv.Codec(0)
 g = torch.Generator(device="cuda").manual_seed(1)
 d = torch.randint(0, 17, (n, H // 8, W // 8), device="cuda", generator=g)
@@ -22,6 +25,9 @@ if "full" in sys.argv:    # every tile of depth 16 (worst case: payload = raw)
 if "d12" in sys.argv:     # 12-bit sensor noise in 16-bit pixels: every tile of depth 12
     imgs = torch.randint(0, 4096, (n, H, W), device="cuda", generator=g, dtype=torch.int16)
 del d, dd, mask, noise, base
+if CROP:
+    W, H = CROP
+    imgs = imgs[:, :H, :W].contiguous()
 maxf = int(codec.L.dbde16_hip_max_frame_bytes(W, H))
 slot = ((maxf + 255) // 256) * 256 if SLOTS else 0
 cap = (n - 1) * slot + maxf if SLOTS else n * maxf

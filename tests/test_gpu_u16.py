@@ -127,7 +127,7 @@ def test_more_chunks_than_resident_workgroups(o16, kind, flags):
 def test_persistent_encoder_geometries(codec, o16, W, H, n, off, kind):
     """The PIX = 2 instance of the persistent encoder: a last tile row that is padded (H % 8), tile counts that leave
     the U16 minima and the payload unaligned (T % 8, odd output offsets), one-tile frames (every chunk nearly
-    empty), frames of many chunks; 1001 wide stays on enc16_kernel.  Every frame byte for byte against the oracle
+    empty), frames of many chunks; 1001 wide takes the any-geometry instance (round 4).  Every frame byte for byte against the oracle
     at small n, a sample of frames otherwise."""
     import torch
     rng = np.random.default_rng(W + 3 * H + n + off + len(kind))
@@ -154,6 +154,37 @@ def test_persistent_encoder_geometries(codec, o16, W, H, n, off, kind):
         if slot == 0:
             assert o[0] == 0 and (o[1:] == np.cumsum(s)[:-1]).all()
             assert (host[off + int(o[-1] + s[-1]):-64] == 0xEE).all() and (host[:off] == 0xEE).all()
+
+
+@pytest.mark.parametrize("W,H,n,shift", [(1001, 67, 180, 0), (1002, 67, 180, 0), (1003, 61, 180, 1), (1004, 67, 180, 0), (1005, 67, 180, 3),
+                                         (1006, 70, 180, 0), (1007, 67, 180, 0), (1000, 67, 180, 1), (1000, 67, 180, 4), (9, 9, 700, 0),
+                                         (15, 8, 600, 1)])
+@pytest.mark.parametrize("kind", ["mixed", "full"])
+def test_persistent_encoder_any_width(codec, o16, W, H, n, shift, kind):
+    """Round 4: widths that are no multiple of 8 pixels (and aligned widths at a base that is not 16-byte aligned) through
+    the persistent encoder as well (encode_kernel<kInRaw, .., PIX = 2>): every count of valid columns in a row's last tile,
+    images that END with their buffer (the batch's last fetch is moved left), a sample of frames byte for byte against the
+    oracle incl. the first and the last, round trip."""
+    import torch
+    rng = np.random.default_rng(W * 5 + H + n + shift + len(kind))
+    imgs_h = make_images(rng, n, W, H, kind)
+    imgs_h[-1, -1, -8:] = rng.integers(0, 65536, 8)
+    flat = torch.empty(shift + n * H * W, dtype=torch.int16, device="cuda")          # the images end where the buffer ends
+    imgs = flat[shift:].view(n, H, W)
+    imgs.copy_(torch.from_numpy(imgs_h.view(np.int16)))
+    maxf = int(codec.L.dbde16_hip_max_frame_bytes(W, H))
+    for slot in (0, ((maxf + 255) // 256) * 256):
+        cap = (n - 1) * slot + maxf if slot else n * maxf
+        buf = torch.full((32 + cap + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        offs, sizes = codec.encode_frames16(imgs, W, H, n, buf, 32, cap, first_index=9, slot_stride=slot)
+        back, res = codec.decode_frames16(buf, 32, cap, offs, W, H, n)
+        codec.sync()
+        assert torch.equal(back, imgs), (W, H, kind, slot)
+        host, o, s = buf.cpu().numpy(), offs.cpu().numpy(), sizes.cpu().numpy()
+        for f in sorted(set([0, 1, n // 2, n - 2, n - 1] + [int(x) for x in rng.integers(0, n, 6)])):
+            want = pack16(o16, imgs_h[f], 9 + f)
+            got = host[32 + int(o[f]): 32 + int(o[f] + s[f])]
+            assert int(s[f]) == len(want) and got.tobytes() == want.tobytes(), (W, H, kind, slot, f)
 
 
 def test_malformed_frames_are_rejected(codec, o16):

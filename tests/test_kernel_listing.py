@@ -79,7 +79,9 @@ PERSISTENT = ["_ZN4dbde13encode_kernelILi0ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde
               # ... one wave per segment of a tile row (round 4)
               "_ZN4dbde13encode_kernelILi4ELb1ELi1EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi4ELb0ELi1EEEvNS_9EncParamsE",
               # DBDE16 through the same kernel (PIX = 2: one 16-bit tile per lane, the same eight 16-byte loads per step)
-              "_ZN4dbde13encode_kernelILi0ELb1ELi2EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0ELi2EEEvNS_9EncParamsE"]
+              "_ZN4dbde13encode_kernelILi0ELb1ELi2EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi0ELb0ELi2EEEvNS_9EncParamsE",
+              # ... and its any-geometry form (round 4)
+              "_ZN4dbde13encode_kernelILi1ELb1ELi2EEEvNS_9EncParamsE", "_ZN4dbde13encode_kernelILi1ELb0ELi2EEEvNS_9EncParamsE"]
 
 
 @pytest.mark.parametrize("mangled", PERSISTENT)

@@ -31,6 +31,7 @@ shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080), 
           (72, 72), (96, 96), (128, 128), (9, 600), (130, 121),   # 65 .. 272 tiles: whole frames per workgroup (encode_mid / decode_mid) and just above
           (160, 120), (176, 144), (200, 152), (104, 100), (224, 200),   # round 4: 65 .. 640 tiles with 8-byte rows: encode_frames_kernel
           (2999, 2001), (1923, 1083), (1935, 1080),                     # round 4: odd rows on dword-aligned fetches (kInRaw4) / last pair of 15 columns (natural)
+          (1081, 1921), (1009, 700),                                    # ... pairs dealt linearly (68 / 64 pairs per tile row); the others above: one wave per row segment (kInRow)
           (1921, 1081), (1001, 999), (64, 64), (8, 8), (61, 59), (33, 31), (512, 8), (24, 16)]
 t0 = time.time()
 frames_done = 0
@@ -77,7 +78,8 @@ o16.dbde16_oracle_pack_frame.argtypes = [C.c_uint64, u16p, C.c_int, C.c_int, u8p
 u16_rounds = max(a.rounds // 4, 1)
 for r in range(u16_rounds):
     # (aligned widths with enough chunks take the persistent encoder, PIX = 2; 1000x1003: T % 8 != 0, unaligned minima)
-    W, H = [(2048, 1536), (1921, 1081), (4096, 3072), (640, 480), (1000, 1003), (1024, 768)][int(rng.integers(0, 6))]
+    # (round 4: widths off 8 pixels with enough chunks take its any-geometry instance)
+    W, H = [(2048, 1536), (1921, 1081), (4096, 3072), (640, 480), (1000, 1003), (1024, 768), (1001, 1003), (1003, 517)][int(rng.integers(0, 8))]
     n = int(rng.choice([1, 3, 16, 40, 64]))
     kind = str(rng.choice(["full", "mixed", "small"]))
     d = rng.integers(0, 17, size=(n, (H + 7) // 8, (W + 7) // 8))

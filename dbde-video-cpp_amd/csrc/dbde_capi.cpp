@@ -582,9 +582,11 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
 // ---- batch decode ----------------------------------------------------------------------------
 #ifndef DBDE_MID_DECODE_TILES
 // Frames of up to this many tiles decode with whole frames per wave (T <= 64, decode_tiny_kernel) or per workgroup
-// (decode_mid_kernel): no index kernel, no chunk.  Measured wall time per step, mid against chunks + index kernel: T = 81 twice as
-// fast, 144 +24 %, 196 equal (mixed) / -14 % (incompressible), 256 -7 %.
-#define DBDE_MID_DECODE_TILES 160
+// (decode_mid_kernel): no index kernel, no chunk.  Measured wall time per step, mid against chunks + index kernel, round 3:
+// T = 81 twice as fast, 144 +24 %, 196 equal (mixed) / -14 % (incompressible), 256 -7 %; with the round-4 form of the kernel
+// (persistent 256-thread workgroups, software-pipelined, wide payload loads, pixels staged): 169 tiles 0.91 -> 0.60 ms,
+// 225 0.48 -> 0.40 (incompressible 0.53 -> 0.475), 240 0.40 -> 0.315, 256 0.416 -> 0.344 (incompressible 0.414 -> 0.429).
+#define DBDE_MID_DECODE_TILES 256
 #endif
 #ifndef DBDE_STAGED_FILL
 // Percent of a workgroup's 512 tile slots that whole tile rows must fill for the staged decode path.  A workgroup's time
@@ -693,7 +695,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
         span_begin(ctx, 2);
         if (pl.kernel == 2) HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
         else if (pl.kernel == 4) HIP_TRY(ctx, launch_decode_frames(tp, (uint32_t)n_frames, ctx->stream));
-        else HIP_TRY(ctx, launch_decode_mid(tp, (uint32_t)n_frames, ctx->stream));
+        else HIP_TRY(ctx, launch_decode_mid(tp, (uint32_t)n_frames, (ctx->exp_flags & 1024u) ? 0u : (uint32_t)ctx->n_cu, ctx->stream));   // (experiment bit 10: three workgroups)
         span_end(ctx);
         return DBDE_HIP_OK;
     }
@@ -920,7 +922,7 @@ int dbde_hip_decode_plan(int W, int H, int n_frames, uint64_t image_address, int
         plan->chunk_tiles = pl.dg.ct;
         plan->n_chunks = pl.n_chunks64;
     } else {
-        plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)mid_threads_for(g.T));
+        plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)mid_decode_threads_for(g.T));
     }
     return DBDE_HIP_OK;
 }

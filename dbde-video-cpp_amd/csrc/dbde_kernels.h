@@ -170,8 +170,10 @@ int encode_blocks_per_cu();
 // Frames of 65 .. 512 tiles, one slot per frame: one tile per lane, as many whole frames per 256 / 512 / 1024-thread
 // workgroup as fit (mid_threads_for), no workspace.
 hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t s);
-uint32_t mid_threads_for(uint32_t T);
-hipError_t launch_decode_mid(const struct DecParams &p, uint32_t n_frames, hipStream_t s);
+uint32_t mid_threads_for(uint32_t T, uint32_t max_threads = 1024u);
+uint32_t mid_decode_threads_for(uint32_t T);   // the decoder's choice (persistent workgroups: smaller ones, more of them per CU)
+// (persistent workgroups, n_cu * 2048 / threads of them; n_cu = 0: three, for tests of the pipelined loop on small batches)
+hipError_t launch_decode_mid(const struct DecParams &p, uint32_t n_frames, uint32_t n_cu, hipStream_t s);
 // Frames of 65 .. 1024 tiles with 8-byte aligned rows, whole frames per workgroup, pixels and stream bytes staged through
 // LDS as aligned 16-byte blocks (encode: one slot per frame).  frames_threads_for: 256 or 512 threads (512 / 1024 tile slots).
 hipError_t launch_encode_frames(const EncParams &p, uint32_t n_frames, hipStream_t s);

@@ -1663,14 +1663,25 @@ __global__ __launch_bounds__(THREADS) void encode_mid_kernel(EncParams p) {
 }
 
 // Threads of the workgroup that whole frames of T tiles (64 < T <= 512) fill best: 256, 512 or 1024.
-uint32_t mid_threads_for(uint32_t T) {
-    uint32_t best = 1024u, best_used = 0u;
-    for (uint32_t th = 256u; th <= 1024u; th *= 2u) {
+#ifndef DBDE_MID_DECODE_MAX_THREADS
+#define DBDE_MID_DECODE_MAX_THREADS 256   // largest workgroup of the (persistent) mid decoder: 256 threads measured best or equal at every fill (96x96, one frame of 144 tiles per workgroup: 0.50 / 0.64 against 0.455 / 0.52 with seven frames on 1024 threads, one workgroup per CU)
+#endif
+uint32_t mid_threads_for(uint32_t T, uint32_t max_threads) {
+    uint32_t best = max_threads, best_used = 0u;
+    for (uint32_t th = 256u; th <= max_threads; th *= 2u) {
         if (th < T) continue;
         const uint32_t used = (th / T) * T;
         if ((uint64_t)used * best > (uint64_t)best_used * th) { best = th; best_used = used; }
     }
     return best;
+}
+
+uint32_t mid_decode_threads_for(uint32_t T) {
+#ifdef DBDE_MID_V1
+    return mid_threads_for(T);
+#else
+    return mid_threads_for(T, T <= (unsigned)DBDE_MID_DECODE_MAX_THREADS ? (unsigned)DBDE_MID_DECODE_MAX_THREADS : 1024u);
+#endif
 }
 
 hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t s) {
@@ -2834,6 +2845,236 @@ __global__ __launch_bounds__(256) void decode_tiny_kernel(DecParams p) {
 // A lane owns ONE tile, a WORKGROUP of 256 / 512 / 1024 threads as many whole frames as fit (mid_threads_for); the
 // frame's validation and the tile's word offset are a segmented scan over the depth bytes through LDS.  No index kernel,
 // no chunk: a 72x72 frame (81 tiles) in a 512-tile chunk behind a one-workgroup-per-frame index kernel ran at 0.22.
+//
+// Round 4, second half: the workgroups are PERSISTENT and the groups of frames they walk are software-pipelined.  A group's
+// life was a chain of four dependent memory round trips (frame offset -> depth bytes -> the three I32 fields -> payload rows)
+// with 24 KB moved per workgroup at the end of it: at eight workgroups per CU that is latency, not bandwidth (72x72: 0.38 of
+// peak with the vector ALU a quarter busy).  Now a workgroup holds, while it decodes group g, the depth / minimum bytes and
+// the fields of group g + G (requested one iteration earlier, all of them in ONE batch as soon as the offset is known) and
+// the offset of group g + 2 G: one exposed round trip per group, the payload rows, and one barrier (the scan's LDS arrays
+// alternate between two sets so that no second barrier is needed before they are written again).
+struct MidMeta {
+    uint32_t d, mn;           // the lane's depth and minimum bytes
+    uint32_t nb, nm, n64;     // the frame's three I32 fields (every lane of a frame asks for the same words)
+};
+
+#ifndef DBDE_MID_V1
+#ifndef DBDE_MID_NO_STAGE
+#define DBDE_MID_NO_STAGE 0   // A/B switch: 1 = tile rows stored straight from the registers at every width
+#endif
+#ifndef DBDE_MID_WAVES
+#define DBDE_MID_WAVES 6   // (the register allocator's target; the 256-thread instance comes out at 64 VGPRs = eight waves per SIMD without scratch, asked for eight it spills)
+#endif
+// STAGED (8-byte aligned image rows: W % 8 == 0 and an 8-byte aligned base): the group's frames are ONE contiguous byte range
+// of the output (frames follow each other in the batch).  Eight 8-byte stores per lane at a stride of W scatter a wave's
+// store over a dozen partial cache lines -- with the payload loads ablated the kernel still took 0.50 of its 0.72 ms on
+// 72x72 frames, without the stores 0.34 -- so the tile rows go into an LDS image of that range (aligned ds_write_b64,
+// placed so that LDS and global addresses agree mod 16) and leave as aligned 16-byte stores, whole cache lines per wave;
+// one more LDS-only barrier per group.
+template <int THREADS, bool STAGED>
+__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void decode_mid_kernel(DecParams p) {   // (1024 threads: one workgroup per CU either way)
+    constexpr int NW = THREADS / 64;
+    __shared__ uint32_t s_tot[2][NW];
+    __shared__ uint32_t s_incl[2][THREADS];
+    // a payload slot per lane (64 bytes + what the last row's three dwords read past them), and in the same memory, later
+    // in a group's life, the image of the group's pixels (STAGED: THREADS / T frames of T tiles, 16 bytes of alignment)
+    constexpr uint32_t kMidSlot = 80u;
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[THREADS * kMidSlot];
+    __shared__ uint32_t s_ok[16];                                                             // (at most 15 frames of 65 tiles)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t T = p.T, fpw = (uint32_t)THREADS / T;      // frames per workgroup
+    const uint32_t fl = tid / T, t = tid - fl * T;            // frame within the workgroup, tile within the frame
+    const uint32_t n_frames = p.n_chunks;                     // (n_chunks carries the frame count here)
+    const uint32_t n_groups = (n_frames + fpw - 1u) / fpw, G = gridDim.x;
+    const bool slot = fl < fpw;
+    const uint32_t first = slot ? fl * T : 0u;                // the frame's first lane
+    const uint64_t need = 32ull + 2ull * T;
+    const uint8_t *s_end = p.stream + p.stream_bytes;
+    // where the lane's tile lies in a frame (the same for every group)
+    const uint32_t ty = t / p.w, tx = t - ty * p.w;
+    const uint32_t Wu = (uint32_t)p.W, x0 = 8u * tx;
+    const uint32_t rm = Wu - x0 < 8u ? Wu - x0 : 8u;                                    // valid columns
+    const uint32_t rv = (uint32_t)p.H - 8u * ty < 8u ? (uint32_t)p.H - 8u * ty : 8u;    // valid rows
+    const uint32_t tile_off = 8u * ty * Wu + x0;                                       // (a frame of <= 1024 tiles)
+    const bool want_results = p.results != nullptr;
+
+    auto is_active = [&](uint32_t g) -> bool { return slot && g < n_groups && g * fpw + fl < n_frames; };
+    auto get_foff = [&](uint32_t g) -> uint64_t { return is_active(g) ? p.frame_offsets[g * fpw + fl] : 0ull; };
+    auto get_meta = [&](uint32_t g, uint64_t foff) -> MidMeta {
+        MidMeta m;
+        m.d = 0; m.mn = 0; m.nb = 0; m.nm = 0; m.n64 = 0;
+        const bool active = is_active(g);
+        const uint8_t *fb = p.stream + foff;
+        if (active && in_extent(foff, need, p.stream_bytes)) {
+            m.d = fb[24u + t]; m.mn = fb[28u + T + t];
+            __builtin_memcpy(&m.nb, fb + 20, 4); __builtin_memcpy(&m.nm, fb + 24 + T, 4); __builtin_memcpy(&m.n64, fb + 28 + 2ull * T, 4);
+        }
+        return m;
+    };
+
+    uint32_t g = blockIdx.x;
+    uint64_t foff_cur = get_foff(g), foff_nxt = get_foff(g + G);
+    // what is carried from one iteration to the next of a group's metadata: depth | minimum << 8, and the frame's n64 field
+    // (all ones when nb or nm is not T: no sum of depths equals that)
+    auto settle = [&](const MidMeta &x, uint32_t &dm, uint32_t &n64x) {
+        dm = x.d | (x.mn << 8);
+        n64x = ((int32_t)x.nb == (int32_t)T && (int32_t)x.nm == (int32_t)T) ? x.n64 : 0xFFFFFFFFu;
+    };
+    uint32_t dm, n64x;
+    settle(get_meta(g, foff_cur), dm, n64x);
+    for (uint32_t par = 0; g < n_groups; g += G, par ^= 1u) {
+        // ---- requests for the groups behind this one (nothing here waits for memory: foff_nxt arrived an iteration ago) ----
+        MidMeta m_nxt = get_meta(g + G, foff_nxt);
+        uint64_t foff_nn = get_foff(g + 2u * G);
+        // ---- this group ----
+        const bool active = is_active(g);
+        const uint32_t f = g * fpw + fl;
+        const uint64_t foff = foff_cur;
+        const bool in_range = active && in_extent(foff, need, p.stream_bytes);
+        const uint32_t d = dm & 0xFFu, mn = dm >> 8;
+        // depth sum and "a depth above 8" count of every frame in one scan: low 20 bits words (<= 1024 * 255), above them flags
+        const uint32_t item = in_range ? (d | (d > 8u ? 1u << 20 : 0u)) : 0u;
+        const uint32_t w_incl = wave_scan_incl(item);
+        s_incl[par][tid] = w_incl;
+        if (lane == 63u) s_tot[par][wave] = w_incl;
+        lds_barrier();   // (LDS only: __syncthreads() would also wait for the prefetch that has just been asked for)
+        // inclusive prefix over the workgroup at lane x: the wave's own scan + the totals of the waves in front of it
+        auto pref = [&](uint32_t x) -> uint32_t {
+            uint32_t a = s_incl[par][x];
+#pragma unroll
+            for (int k = 0; k < NW - 1; k++) a += (uint32_t)k < (x >> 6) ? s_tot[par][k] : 0u;
+            return a;
+        };
+        // (lanes without a frame take the values of lane 0's: in bounds, never used)
+        const uint32_t base = first ? pref(active ? first - 1u : 0u) : 0u;
+        const uint32_t upto = pref(active ? first + T - 1u : 0u);
+        const uint32_t mine = pref(tid);
+        const uint32_t total = (upto - base) & 0xFFFFFu, n_bad = (upto - base) >> 20;
+        const uint32_t prefix = (mine - item - base) & 0xFFFFFu;   // payload words of the frame in front of this tile
+        const bool ok = in_range && n64x == total && n_bad == 0u && in_extent(foff, need + 8ull * total, p.stream_bytes);
+        // the frame's result record (dbde_unpack_frame's return value): its header words are asked for here, in front of
+        // the payload rows, and consumed behind them -- the same round trip
+        uint32_t h_field = 0;
+        uint64_t h_index = 0, h_elapsed = 0;
+        const bool record = active && t == 0u && want_results;
+        if (record && in_extent(foff, 20, p.stream_bytes)) {
+            const uint8_t *fb = p.stream + foff;
+            __builtin_memcpy(&h_field, fb, 4); __builtin_memcpy(&h_index, fb + 4, 8); __builtin_memcpy(&h_elapsed, fb + 12, 8);
+        }
+        // The tile's payload: 8 d contiguous bytes, fetched as ceil(d / 2) 16-byte pieces from its first byte on (eight
+        // 8-byte row loads per lane, most of their bytes fetched twice or more, were a third of the kernel's time) and put
+        // down in a slot of the lane's own in LDS, from which the rows are cut as the chunk decoder cuts them
+        // (unpack_tile_from_lds: three aligned dwords + v_alignbyte per row).  The one wait behind the loads is a wait the
+        // whole loop body shares: behind it the prefetched words of the next group have arrived as well (they were asked
+        // for earlier), and nothing behind the group's stores waits for memory again.
+        const uint8_t *pay = p.stream + foff + need + 8ull * prefix;
+        const uint32_t npc_all = (d + 1u) >> 1;
+#ifdef DBDE_MID_ABLATE_LOADS
+        const bool whole = false;
+#else
+        const bool whole = ok && d != 0u && pay + 16u * npc_all <= s_end;   // every piece lies inside the readable extent
+#endif
+        const uint32_t npc = whole ? npc_all : 0u;
+        u32x4_t q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+        if (npc > 0u) __builtin_memcpy(&q0, pay, 16);
+        if (npc > 1u) __builtin_memcpy(&q1, pay + 16, 16);
+        if (npc > 2u) __builtin_memcpy(&q2, pay + 32, 16);
+        if (npc > 3u) __builtin_memcpy(&q3, pay + 48, 16);
+        // First look at anything this iteration asked for.  (Left to itself the scheduler moves the consumers of the
+        // prefetched words up to their loads to shorten live ranges -- a wait for the round trip that was to be hidden,
+        // seen in the listing -- and a look at them BEHIND the stores would wait for the stores too.)
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3),
+                          "+v"(m_nxt.d), "+v"(m_nxt.mn), "+v"(m_nxt.nb), "+v"(m_nxt.nm), "+v"(m_nxt.n64), "+v"(foff_nn),
+                          "+v"(h_field), "+v"(h_index), "+v"(h_elapsed) :: "memory");
+        const uint32_t slot = kMidSlot * tid;
+        {
+            u32x4_t *sl = reinterpret_cast<u32x4_t *>(s_lds + slot);
+            if (npc > 0u) sl[0] = q0;
+            if (npc > 1u) sl[1] = q1;
+            if (npc > 2u) sl[2] = q2;
+            if (npc > 3u) sl[3] = q3;
+        }
+#ifndef DBDE_MID_ABLATE_LOADS
+        if (ok && d != 0u && !whole) {   // the stream's last bytes: nothing past the extent
+            for (uint32_t b = 0; b < 8u * d; b++) s_lds[slot + b] = pay[b];
+        }
+#endif
+        uint32_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = 0;
+        if (ok) unpack_tile_from_lds<false>(s_lds, slot, d, mn, v);   // (a flat tile: the minimum, whatever the slot holds)
+        if (STAGED) lds_barrier();   // the payload slots and the image of the group's pixels share the memory
+        if (ok) {   // (a rejected frame's image stays untouched, dbde_util.cpp:296-303)
+            uint8_t *dst = p.images + (size_t)f * p.frame_pixels + tile_off;
+            // (STAGED: where the tile's first row lies in the image of the group's byte range; the range starts at 0 or 8 mod 16)
+            const uint32_t px0 = ((uint32_t)(reinterpret_cast<uintptr_t>(p.images) + (size_t)(g * fpw) * p.frame_pixels) & 15u) +
+                                 fl * (uint32_t)p.frame_pixels + tile_off;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t lo = v[2 * r], hi = v[2 * r + 1];
+#ifdef DBDE_MID_ABLATE_STORES
+                if (lo == 0x12345678u && hi == 0x9ABCDEF0u) {
+#else
+                if (STAGED) {
+                    if ((uint32_t)r < rv) lds_store_u64_any(s_lds, px0 + (uint32_t)r * Wu, lo, hi);   // (8-byte aligned)
+                } else if ((uint32_t)r < rv) {   // only the valid region is written (dbde_util.cpp:281-289)
+#endif
+                    uint8_t *row = dst + (size_t)r * Wu;
+                    const uint64_t q = ((uint64_t)hi << 32) | lo;
+                    if (rm == 8u) store_u64_any(row, q);
+                    else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; k++)
+                            if (k < rm) row[k] = (uint8_t)(q >> (8u * k));
+                    }
+                }
+            }
+        }
+        if (STAGED) {
+            if (active && t == 0u) s_ok[fl] = ok ? 1u : 0u;
+            lds_barrier();
+            const uint32_t P = (uint32_t)p.frame_pixels;
+            const uint32_t nfr = n_frames - g * fpw < fpw ? n_frames - g * fpw : fpw;      // frames of this group
+            uint8_t *g0 = p.images + (size_t)(g * fpw) * p.frame_pixels;                   // its first byte in the output
+            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 15u);         // 0 or 8
+            const uint32_t nbytes = nfr * P;
+            uint32_t okm = 0;
+            for (uint32_t k = 0; k < nfr; k++) okm |= s_ok[k] << k;
+            if (okm == (1u << nfr) - 1u) {   // every frame decoded: aligned 16-byte blocks, an 8-byte half at either end
+                const uint32_t n_blocks = (sh + nbytes + 15u) >> 4;
+                for (uint32_t j = tid; j < n_blocks; j += (uint32_t)THREADS) {
+                    uint8_t *dst = g0 - sh + 16ull * j;
+                    const bool upper_only = j == 0u && sh != 0u, lower_only = 16u * j + 16u > sh + nbytes;
+                    if (!upper_only && !lower_only) {
+                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(s_lds + 16u * j);
+                        if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(dst));
+                        else *reinterpret_cast<u32x4_t *>(dst) = q;
+                    } else if (!(upper_only && lower_only)) {
+                        const uint32_t o = upper_only ? 8u : 0u;
+                        *reinterpret_cast<uint64_t *>(dst + o) = *reinterpret_cast<const uint64_t *>(s_lds + 16u * j + o);
+                    }
+                }
+            } else {                          // a rejected frame's image stays untouched: 8 bytes at a time, frame by frame
+                for (uint32_t u = tid; 8u * u < nbytes; u += (uint32_t)THREADS) {
+                    const uint32_t o = 8u * u;
+                    if ((okm >> (o / P)) & 1u) *reinterpret_cast<uint64_t *>(g0 + o) = *reinterpret_cast<const uint64_t *>(s_lds + sh + o);
+                }
+            }
+        }
+        if (record) {
+            FrameResultDev *r = reinterpret_cast<FrameResultDev *>(p.results) + f;
+            r->u64s = (h_field == 2u && ok) ? 2u : 0xFFFFFFFFu;   // dbde_util.cpp:335,342
+            r->pad_ = 0;
+            r->index = h_index;
+            r->elapsed_ns = f64_to_u64_x86(__longlong_as_double((long long)h_elapsed));
+            r->consumed = ok ? need + 8ull * total : 20ull;
+        }
+        foff_cur = foff_nxt; foff_nxt = foff_nn;
+        settle(m_nxt, dm, n64x);
+    }
+}
+
+#else   // -DDBDE_MID_V1: one workgroup per group of frames, four dependent round trips (A/B against the pipelined form)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void decode_mid_kernel(DecParams p) {
     constexpr int NW = THREADS / 64;
@@ -2904,14 +3145,40 @@ __global__ __launch_bounds__(THREADS) void decode_mid_kernel(DecParams p) {
     store_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
 }
 
-hipError_t launch_decode_mid(const DecParams &p, uint32_t n_frames, hipStream_t s) {
+#endif
+
+hipError_t launch_decode_mid(const DecParams &p, uint32_t n_frames, uint32_t n_cu, hipStream_t s) {
     DecParams q = p;
     q.n_chunks = n_frames;
-    const uint32_t th = mid_threads_for(p.T), per_wg = th / p.T;
-    const dim3 grid((n_frames + per_wg - 1u) / per_wg);
+    const uint32_t th = mid_decode_threads_for(p.T), per_wg = th / p.T;
+    uint32_t groups = (n_frames + per_wg - 1u) / per_wg;
+#ifndef DBDE_MID_V1
+    // 8-byte aligned image rows: pixels staged in LDS, aligned 16-byte stores (decode_mid_kernel<., true>)
+    const bool staged = p.W % 8 == 0 && (reinterpret_cast<uintptr_t>(p.images) & 7u) == 0u && !DBDE_MID_NO_STAGE;
+    auto go = [&](auto kernel, uint32_t threads) {
+        // persistent: as many workgroups as the device holds (n_cu = 0, tests: three, so that small batches walk the
+        // pipelined loop too)
+        static int resident_per_cu[2][3] = {{0, 0, 0}, {0, 0, 0}};   // (asked once per instance)
+        int &per_cu = resident_per_cu[staged ? 1 : 0][threads == 256u ? 0 : (threads == 512u ? 1 : 2)];
+        if (per_cu < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, 0) != hipSuccess || per_cu < 1)) per_cu = 1;
+        const uint32_t resident = n_cu ? n_cu * (uint32_t)per_cu : 3u;
+        hipLaunchKernelGGL(kernel, dim3(groups < resident ? groups : resident), dim3(threads), 0, s, q);
+    };
+    if (staged) {
+        if (th == 256u) go(decode_mid_kernel<256, true>, 256u);
+        else if (th == 512u) go(decode_mid_kernel<512, true>, 512u);
+        else go(decode_mid_kernel<1024, true>, 1024u);
+    } else {
+        if (th == 256u) go(decode_mid_kernel<256, false>, 256u);
+        else if (th == 512u) go(decode_mid_kernel<512, false>, 512u);
+        else go(decode_mid_kernel<1024, false>, 1024u);
+    }
+#else
+    const dim3 grid(groups);
     if (th == 256u) hipLaunchKernelGGL(decode_mid_kernel<256>, grid, dim3(256), 0, s, q);
     else if (th == 512u) hipLaunchKernelGGL(decode_mid_kernel<512>, grid, dim3(512), 0, s, q);
     else hipLaunchKernelGGL(decode_mid_kernel<1024>, grid, dim3(1024), 0, s, q);
+#endif
     return hipGetLastError();
 }
 

@@ -887,7 +887,7 @@ def test_tiny_frames_many_per_wave(codec, codec_staged_decode, oracle, W, H, n, 
                                    (72, 72, 7), (104, 100, 33), (200, 150, 19), (168, 161, 10), (224, 200, 5), (176, 144, 1),
                                    (520, 65, 9), (8, 5200, 3)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
-def test_mid_frames_many_per_workgroup(codec, codec_staged_decode, oracle, W, H, n, mode):
+def test_mid_frames_many_per_workgroup(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, mode):
     """Frames of 65 .. 512 tiles (72 .. 180 pixels a side): one tile per lane, as many whole frames per 256 / 512 / 1024
     thread workgroup as fit (encode_mid_kernel for slots; decode_mid_kernel where it is the faster form); every frame
     byte for byte against the oracle, both layouts, partial tiles, frame counts that leave the last workgroup part empty."""
@@ -900,12 +900,35 @@ def test_mid_frames_many_per_workgroup(codec, codec_staged_decode, oracle, W, H,
         for f in range(n):
             assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
         total = int((offs[-1] + sizes[-1]).item())
-        for dec in (codec, codec_staged_decode):      # the default forms, and the staged whole-frame decoder where it applies
+        # the default forms, the staged whole-frame decoder where it applies, and decode_mid_kernel on three persistent
+        # workgroups: every workgroup walks its software-pipelined loop several times (metadata of the next group and the
+        # offset of the one after it in flight), the last iterations with groups that do not exist
+        for dec in (codec, codec_staged_decode, codec_three_workgroups):
             canvas = torch.full_like(imgs, 0xEE)
             back, res = dec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
             dec.sync()
             assert torch.equal(back, imgs), (W, H, mode, slot)
             assert dec.parse_results(res) == [(2, 50 + f, 0, len(frames[f])) for f in range(n)]
+
+
+def _codec_with_experiment(dv, bits):
+    import os
+    old = os.environ.get("DBDE_HIP_EXPERIMENT")
+    os.environ["DBDE_HIP_EXPERIMENT"] = str(bits | int(old or "0", 0))
+    c = dv.Codec(0)
+    if old is None:
+        del os.environ["DBDE_HIP_EXPERIMENT"]
+    else:
+        os.environ["DBDE_HIP_EXPERIMENT"] = old
+    return c
+
+
+@pytest.fixture(scope="module")
+def codec_three_workgroups(dv):
+    """A context whose decode_mid_kernel launches have three (persistent) workgroups ($DBDE_HIP_EXPERIMENT bit 10)."""
+    c = _codec_with_experiment(dv, 1024)
+    yield c
+    c.close()
 
 
 @pytest.fixture(scope="module")
@@ -924,10 +947,10 @@ def codec_staged_decode(dv):
     c.close()
 
 
-@pytest.mark.parametrize("which", ["default", "staged"])
+@pytest.mark.parametrize("which", ["default", "staged", "three_workgroups"])
 @pytest.mark.parametrize("W,H,n", [(72, 72, 50), (160, 120, 23), (96, 96, 61), (200, 150, 9)])
-def test_staged_frame_decoder_takes_any_offsets_and_rejects_like_the_reference(codec, codec_staged_decode, oracle, W, H, n, which):
-    codec = codec if which == "default" else codec_staged_decode
+def test_staged_frame_decoder_takes_any_offsets_and_rejects_like_the_reference(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, which):
+    codec = {"default": codec, "staged": codec_staged_decode, "three_workgroups": codec_three_workgroups}[which]
     """decode_frames_kernel: frames wherever they lie (concatenated: every alignment mod 16; a stream base that is odd), a
     readable extent that ends with the last frame, and malformed frames among good ones -- nb / nm / n64 wrong, a depth
     byte above 8, a truncated frame, a wild offset: rejected with u64s = 0xFFFFFFFF and consumed = 20 (dbde_util.cpp:

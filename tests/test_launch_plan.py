@@ -82,16 +82,16 @@ def test_unaligned_image_base_changes_the_form():
 @pytest.mark.parametrize("W,H,T,enc,dec,threads", [
     (8, 8, 1, TINY, TINY, 256), (64, 64, 64, TINY, TINY, 256),
     # 8-byte aligned rows, frames and buffers whole 16-byte blocks (round 4): whole frames per workgroup, staged through LDS
-    # (encode; the decode side keeps decode_mid_kernel up to 160 tiles and the chunk kernels above: the staged decoder
-    # measured no faster and is an experiment switch)
+    # (encode; the decode side keeps decode_mid_kernel -- persistent, software-pipelined from the second half of round 4 --
+    # up to 256 tiles and the chunk kernels above: the staged whole-frame decoder measured no faster and is an experiment switch)
     (72, 72, 81, FRAMES, MID, 256),          # 6 frames in 512 tile slots (95 %)
     (96, 96, 144, FRAMES, MID, 512),         # 7 frames in 1024 slots (98 %; 3 in 512: 84 %)
-    (128, 128, 256, FRAMES, 0, 256),         # 2 frames in 512 slots
+    (128, 128, 256, FRAMES, MID, 256),       # 2 frames in 512 slots
     (160, 120, 300, FRAMES, 0, 512),         # 3 frames in 1024 slots (88 %; one in 512: 59 %)
     (176, 144, 396, FRAMES, 0, 256),         # one frame in 512 slots = two in 1024 (77 %): the smaller workgroup
     (320, 240, 1200, PERSISTENT, 0, 512),    # above 640 tiles: the chunk kernels
     # rows that are not 8-byte aligned keep the one-tile-per-lane forms
-    (75, 70, 90, MID, MID, 1024), (100, 100, 169, MID, 0, 512),
+    (75, 70, 90, MID, MID, 1024), (100, 100, 169, MID, MID, 512), (136, 128, 272, FRAMES, 0, 512),
 ])
 def test_small_frames(W, H, T, enc, dec, threads):
     slot = ((32 + 66 * T + 255) // 256) * 256
@@ -100,6 +100,8 @@ def test_small_frames(W, H, T, enc, dec, threads):
     assert e["kernel"] == enc and d["kernel"] == dec, (e, d)
     if enc in (TINY, MID, FRAMES):
         assert e["threads"] == threads
+    if dec == MID:
+        assert d["threads"] == 256          # the persistent mid decoder: 256-thread workgroups at every fill
     # an image base that is not a multiple of 16 bytes: the staged form does not apply
     if enc == FRAMES:
         assert dv.encode_plan(W, H, 100000, slot_stride=slot, image_address=8)["kernel"] in (MID, PERSISTENT)

@@ -581,8 +581,9 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
 
 // ---- batch decode ----------------------------------------------------------------------------
 #ifndef DBDE_MID_DECODE_TILES
-// Frames of up to this many tiles decode with whole frames per wave (T <= 64, decode_tiny_kernel) or per workgroup
-// (decode_mid_kernel): no index kernel, no chunk.  Measured wall time per step, mid against chunks + index kernel, round 3:
+// Frames of up to this many tiles decode with whole frames per workgroup (decode_mid_kernel: one tile per lane, from one-tile
+// frames up; rounds 2-3 had a kernel of its own for T <= 64, whole frames per wave, which the persistent form beat at every
+// size -- 64x64 0.49 -> 0.63, 32x32 0.33 -> 0.56, 8x8 0.19 -> 0.30): no index kernel, no chunk.  Measured wall time per step, mid against chunks + index kernel, round 3:
 // T = 81 twice as fast, 144 +24 %, 196 equal (mixed) / -14 % (incompressible), 256 -7 %; with the round-4 form of the kernel
 // (persistent 256-thread workgroups, software-pipelined, wide payload loads, pixels staged): 169 tiles 0.91 -> 0.60 ms,
 // 225 0.48 -> 0.40 (incompressible 0.53 -> 0.475), 240 0.40 -> 0.315, 256 0.416 -> 0.344 (incompressible 0.414 -> 0.429).
@@ -605,7 +606,7 @@ struct DecPlan {
     DecGeom dg;
     uint64_t n_chunks64;
     bool self_index, fused;
-    int kernel;            // 0 = chunk kernels, 2 = decode_tiny_kernel, 3 = decode_mid_kernel, 4 = decode_frames_kernel
+    int kernel;            // 0 = chunk kernels, 3 = decode_mid_kernel, 4 = decode_frames_kernel
 };
 static DecPlan plan_decode(const Geometry &g, int W, int n_frames, uintptr_t ib, int n_cu, uint32_t exp_flags) {
     DecPlan pl;
@@ -662,7 +663,7 @@ static DecPlan plan_decode(const Geometry &g, int W, int n_frames, uintptr_t ib,
     // device's workgroup slots (four per CU); correctness does not depend on that, only the latency does.
     pl.fused = !pl.self_index && pl.n_chunks64 <= 4ull * (uint64_t)n_cu && !(exp_flags & 8u);
     // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup
-    pl.kernel = g.T <= 64u ? 2 : (g.T <= (unsigned)DBDE_MID_DECODE_TILES ? 3 : 0);
+    pl.kernel = g.T <= (unsigned)DBDE_MID_DECODE_TILES ? 3 : 0;
 #ifndef DBDE_NO_FRAMES
     if ((exp_flags & 256u) && g.T > 64u && g.T <= (unsigned)DBDE_FRAMES_DECODE_TILES && frames_geometry(g, W, ib)) pl.kernel = 4;
 #endif
@@ -693,8 +694,7 @@ int dbde_hip_decode_frames(dbde_hip_ctx *ctx, const uint8_t *d_stream, size_t st
         tp.images = d_images; tp.results = d_results; tp.frame_pixels = g.pixels;
         tp.W = W; tp.H = H; tp.w = g.w; tp.h = g.h; tp.T = g.T;
         span_begin(ctx, 2);
-        if (pl.kernel == 2) HIP_TRY(ctx, launch_decode_tiny(tp, (uint32_t)n_frames, ctx->stream));
-        else if (pl.kernel == 4) HIP_TRY(ctx, launch_decode_frames(tp, (uint32_t)n_frames, ctx->stream));
+        if (pl.kernel == 4) HIP_TRY(ctx, launch_decode_frames(tp, (uint32_t)n_frames, ctx->stream));
         else HIP_TRY(ctx, launch_decode_mid(tp, (uint32_t)n_frames, (ctx->exp_flags & 1024u) ? 0u : (uint32_t)ctx->n_cu, ctx->stream));   // (experiment bit 10: three workgroups)
         span_end(ctx);
         return DBDE_HIP_OK;
@@ -922,7 +922,7 @@ int dbde_hip_decode_plan(int W, int H, int n_frames, uint64_t image_address, int
         plan->chunk_tiles = pl.dg.ct;
         plan->n_chunks = pl.n_chunks64;
     } else {
-        plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)mid_decode_threads_for(g.T));
+        plan->threads = pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)mid_decode_threads_for(g.T);
     }
     return DBDE_HIP_OK;
 }

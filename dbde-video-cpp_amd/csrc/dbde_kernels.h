@@ -187,9 +187,6 @@ hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);
 // frame's whole depth array (few small frames); 2 = no index kernel either, the workgroups exchange their chunks' depth
 // sums through p.fuse_rec (few LARGE frames: launches that fit the device's workgroup slots)
 hipError_t launch_decode(const DecParams &p, int img_mode, int index_mode, hipStream_t s);
-// Frames of at most 64 tiles: one tile per lane, 64 / T frames per wave, validation and offsets by a segmented wave scan
-// (no index kernel, no workspace).
-hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t s);
 hipError_t launch_synth(int mode, uint64_t seed, uint64_t first_frame, int n_frames, int W, int H,
                         uint8_t *d_images, hipStream_t s);
 // Serial frame-to-frame hop over a concatenated stream (one wave); see dbde_hip_index_stream.

@@ -1560,7 +1560,7 @@ hipError_t launch_encode_small(const EncParams &p, bool fast_in, bool aligned_ou
 // ---------------------------------------------------------------------------------------
 // ENCODE, tiny frames (T <= 64 tiles), one slot per frame: one tile per lane, several frames per wave
 // ---------------------------------------------------------------------------------------
-// The mirror of decode_tiny_kernel (the reference's randomized test packs 1024 single-tile frames,
+// The mirror of the small-frame decoder, decode_mid_kernel (the reference's randomized test packs 1024 single-tile frames,
 // dbde_util_test.cpp:66-96): a 1024-tile chunk per frame leaves the lanes empty and a record round trip per frame is all
 // the kernels above would do.  A lane owns ONE tile (clamp-to-edge load: the constant padding of dbde_util.cpp:105-135),
 // a wave 64 / T whole frames; the tile's word offset in its frame and the frame's n64 are a segmented wave scan; the
@@ -1677,11 +1677,7 @@ uint32_t mid_threads_for(uint32_t T, uint32_t max_threads) {
 }
 
 uint32_t mid_decode_threads_for(uint32_t T) {
-#ifdef DBDE_MID_V1
-    return mid_threads_for(T);
-#else
     return mid_threads_for(T, T <= (unsigned)DBDE_MID_DECODE_MAX_THREADS ? (unsigned)DBDE_MID_DECODE_MAX_THREADS : 1024u);
-#endif
 }
 
 hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t s) {
@@ -2209,7 +2205,11 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(DecParams p) {
     const uint32_t c = SELF_INDEX ? blockIdx.x : xcd_local_chunk(blockIdx.x, p.n_chunks);
     const uint32_t f = c / p.chunks_per_frame;
     const uint32_t cf = c - f * p.chunks_per_frame;
+#ifdef DBDE_DEC_FAKE_INDEX   // (probe: what the index round trip costs -- one slot per frame at abbench's stride, every tile of depth 8)
+    const uint64_t foff = (uint64_t)f * (((32ull + 66ull * p.T) + 255ull) / 256ull * 256ull);
+#else
     const uint64_t foff = p.frame_offsets[f];
+#endif
     const uint8_t *fb = p.stream + foff;
     const uint32_t t_begin = dec_chunk_begin(p.geom, cf);
     const uint32_t n_tiles = dec_chunk_begin(p.geom, cf + 1u) - t_begin;   // <= 512
@@ -2415,9 +2415,14 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(DecParams p) {
         SF_MARK(3);
     } else {
         // everything the address arithmetic needs, requested together
+#ifdef DBDE_DEC_FAKE_INDEX
+        const uint32_t ok = 1u;
+        w_begin = 8u * t_begin; w_end = 8u * (t_begin + n_tiles);
+#else
         const uint32_t ok = p.frame_ok[f];
         const uint32_t *co = p.chunk_off + (size_t)f * (p.chunks_per_frame + 1u) + cf;
         w_begin = co[0]; w_end = co[1];
+#endif
 #ifndef DBDE_IDX_SERIAL
         // ... and really together: without this the compiler sinks the loads behind the branch (three dependent
         // scalar round trips before the first payload byte is requested)
@@ -2768,83 +2773,14 @@ __global__ __launch_bounds__(THREADS) void decode_kernel(DecParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// DECODE, tiny frames (T <= 64 tiles: up to 64x64 pixels): one tile per lane, several frames per wave
+// DECODE, small frames (T <= DBDE_MID_DECODE_TILES = 256 tiles, from single-tile frames up): whole frames per workgroup
 // ---------------------------------------------------------------------------------------
 // The reference's own randomized test decodes 1024 single-tile frames (dbde_util_test.cpp:66-96,366); thumbnails are the
-// same regime.  A workgroup per chunk leaves 511 of 512 tile slots empty there and the index kernel (a workgroup per
-// frame) costs more than the decode it serves (64x64 x 262,144 frames: index 2.6 ms, decode 1.1 ms, 0.18 of peak
-// together).  Here a lane owns ONE tile and a wave 64 / T whole frames: the frame's validation (dbde_util.cpp:295-303,
-// plus depth <= 8 and the readable extent) and the tile's word offset are a segmented wave scan over the depth bytes --
-// no index kernel, no LDS, no barrier -- and a tile row is the 8 bytes at byte r * d of the tile's payload, fetched
-// straight from the stream (rows of neighbouring lanes share cache lines).
-__global__ __launch_bounds__(256) void decode_tiny_kernel(DecParams p) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t T = p.T, fpw = 64u / T;                 // frames per wave
-    const uint32_t fl = lane / T, t = lane - fl * T;        // frame within the wave, tile within the frame
-    const uint32_t f = (blockIdx.x * 4u + wave) * fpw + fl;
-    const bool active = fl < fpw && f < p.n_chunks;          // (n_chunks carries the frame count here)
-    const uint64_t need = 32ull + 2ull * T;
-    const uint64_t foff = active ? p.frame_offsets[f] : 0ull;
-    const bool in_range = active && in_extent(foff, need, p.stream_bytes);
-    const uint8_t *fb = p.stream + foff;
-    uint32_t d = 0, mn = 0;
-    if (in_range) { d = fb[24u + t]; mn = fb[28u + T + t]; }
-    // depth sum and "a depth above 8" count of every frame in one scan: low 16 bits words (<= 64 * 255), high bits flags
-    const uint32_t item = in_range ? (d | (d > 8u ? 1u << 16 : 0u)) : 0u;
-    const uint32_t incl = wave_scan_incl(item);
-    const uint32_t first = fl * T;                            // the frame's first lane
-    const uint32_t base = (uint32_t)__shfl((int)(incl - item), (int)(first < 64u ? first : 0u), 64);
-    const uint32_t upto = (uint32_t)__shfl((int)incl, (int)(first + T - 1u < 64u ? first + T - 1u : 63u), 64);
-    const uint32_t total = (upto - base) & 0xFFFFu, n_bad = (upto - base) >> 16;
-    const uint32_t prefix = (incl - item - base) & 0xFFFFu;  // payload words of the frame in front of this tile
-    bool ok = in_range;
-    if (ok) {
-        const int32_t nb = (int32_t)load_u32_bytes(fb + 20), nm = (int32_t)load_u32_bytes(fb + 24 + T);
-        const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
-        ok = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && n_bad == 0u &&
-             in_extent(foff, need + 8ull * total, p.stream_bytes);
-    }
-    if (active && t == 0u && p.results) {   // the frame's result record: dbde_unpack_frame's return value
-        uint32_t field = 0;
-        uint64_t index = 0, elapsed = 0;
-        if (in_extent(foff, 20, p.stream_bytes)) {
-            field = load_u32_bytes(fb);
-            index = load_u64_bytes(fb + 4);
-            elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
-        }
-        FrameResultDev *r = reinterpret_cast<FrameResultDev *>(p.results) + f;
-        r->u64s = (field == 2u && ok) ? 2u : 0xFFFFFFFFu;   // dbde_util.cpp:335,342
-        r->pad_ = 0;
-        r->index = index;
-        r->elapsed_ns = elapsed;
-        r->consumed = ok ? need + 8ull * total : 20ull;
-    }
-    if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
-    const uint8_t *pay = fb + need + 8ull * prefix, *s_end = p.stream + p.stream_bytes;
-    const uint32_t mn4 = mn * 0x01010101u;
-    uint32_t v[16];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint64_t row = 0;
-        if (d != 0u) {
-            const uint8_t *q = pay + (uint32_t)r * d;
-            if (q + 8 <= s_end) row = load_u64_any(q);
-            else for (uint32_t b = 0; b < d; b++) row |= (uint64_t)q[b] << (8u * b);   // the stream's last bytes: nothing past the extent
-        }
-        uint32_t lo, hi;
-        expand_row(row, d, lo, hi);
-        v[2 * r] = add_bytes(lo, mn4);
-        v[2 * r + 1] = add_bytes(hi, mn4);
-    }
-    store_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
-}
-
-// ---------------------------------------------------------------------------------------
-// DECODE, frames just above the tiny path (64 < T <= kMidDecodeTiles): decode_tiny_kernel one level up
-// ---------------------------------------------------------------------------------------
-// A lane owns ONE tile, a WORKGROUP of 256 / 512 / 1024 threads as many whole frames as fit (mid_threads_for); the
-// frame's validation and the tile's word offset are a segmented scan over the depth bytes through LDS.  No index kernel,
-// no chunk: a 72x72 frame (81 tiles) in a 512-tile chunk behind a one-workgroup-per-frame index kernel ran at 0.22.
+// same regime.  A workgroup per 512-tile chunk leaves most tile slots empty there and the index kernel (a workgroup per
+// frame) costs more than the decode it serves (64x64 x 262,144 frames: index 2.6 ms, decode 1.1 ms, 0.18 of peak together;
+// a 72x72 frame in a chunk: 0.22).  Here a lane owns ONE tile, a WORKGROUP of 256 threads as many whole frames as fit
+// (mid_decode_threads_for); the frame's validation (dbde_util.cpp:295-303, plus depth <= 8 and the readable extent) and
+// the tile's word offset are a segmented scan over the depth bytes through LDS.  No index kernel, no chunk.
 //
 // Round 4, second half: the workgroups are PERSISTENT and the groups of frames they walk are software-pipelined.  A group's
 // life was a chain of four dependent memory round trips (frame offset -> depth bytes -> the three I32 fields -> payload rows)
@@ -2858,7 +2794,6 @@ struct MidMeta {
     uint32_t nb, nm, n64;     // the frame's three I32 fields (every lane of a frame asks for the same words)
 };
 
-#ifndef DBDE_MID_V1
 #ifndef DBDE_MID_NO_STAGE
 #define DBDE_MID_NO_STAGE 0   // A/B switch: 1 = tile rows stored straight from the registers at every width
 #endif
@@ -2880,7 +2815,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
     // in a group's life, the image of the group's pixels (STAGED: THREADS / T frames of T tiles, 16 bytes of alignment)
     constexpr uint32_t kMidSlot = 80u;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[THREADS * kMidSlot];
-    __shared__ uint32_t s_ok[16];                                                             // (at most 15 frames of 65 tiles)
+    __shared__ uint32_t s_ok[THREADS];   // per frame of the group: decoded (as many frames as lanes when T = 1)
+    __shared__ uint32_t s_bad[2];        // ... and "a frame of the group was rejected", alternating like the scan's arrays
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t T = p.T, fpw = (uint32_t)THREADS / T;      // frames per workgroup
     const uint32_t fl = tid / T, t = tid - fl * T;            // frame within the workgroup, tile within the frame
@@ -2912,6 +2848,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
         return m;
     };
 
+    if (STAGED && tid == 0u) { s_bad[0] = 0u; s_bad[1] = 0u; }
     uint32_t g = blockIdx.x;
     uint64_t foff_cur = get_foff(g), foff_nxt = get_foff(g + G);
     // what is carried from one iteration to the next of a group's metadata: depth | minimum << 8, and the frame's n64 field
@@ -2938,6 +2875,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
         s_incl[par][tid] = w_incl;
         if (lane == 63u) s_tot[par][wave] = w_incl;
         lds_barrier();   // (LDS only: __syncthreads() would also wait for the prefetch that has just been asked for)
+        if (STAGED && tid == 0u) s_bad[par ^ 1u] = 0u;   // (the previous group's flag: everybody has looked at it by now)
         // inclusive prefix over the workgroup at lane x: the wave's own scan + the totals of the waves in front of it
         auto pref = [&](uint32_t x) -> uint32_t {
             uint32_t a = s_incl[par][x];
@@ -3031,16 +2969,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
             }
         }
         if (STAGED) {
-            if (active && t == 0u) s_ok[fl] = ok ? 1u : 0u;
+            if (active && t == 0u) { s_ok[fl] = ok ? 1u : 0u; if (!ok) s_bad[par] = 1u; }
             lds_barrier();
             const uint32_t P = (uint32_t)p.frame_pixels;
             const uint32_t nfr = n_frames - g * fpw < fpw ? n_frames - g * fpw : fpw;      // frames of this group
             uint8_t *g0 = p.images + (size_t)(g * fpw) * p.frame_pixels;                   // its first byte in the output
             const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 15u);         // 0 or 8
             const uint32_t nbytes = nfr * P;
-            uint32_t okm = 0;
-            for (uint32_t k = 0; k < nfr; k++) okm |= s_ok[k] << k;
-            if (okm == (1u << nfr) - 1u) {   // every frame decoded: aligned 16-byte blocks, an 8-byte half at either end
+            if (s_bad[par] == 0u) {   // every frame decoded: aligned 16-byte blocks, an 8-byte half at either end
                 const uint32_t n_blocks = (sh + nbytes + 15u) >> 4;
                 for (uint32_t j = tid; j < n_blocks; j += (uint32_t)THREADS) {
                     uint8_t *dst = g0 - sh + 16ull * j;
@@ -3057,7 +2993,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
             } else {                          // a rejected frame's image stays untouched: 8 bytes at a time, frame by frame
                 for (uint32_t u = tid; 8u * u < nbytes; u += (uint32_t)THREADS) {
                     const uint32_t o = 8u * u;
-                    if ((okm >> (o / P)) & 1u) *reinterpret_cast<uint64_t *>(g0 + o) = *reinterpret_cast<const uint64_t *>(s_lds + sh + o);
+                    if (s_ok[o / P]) *reinterpret_cast<uint64_t *>(g0 + o) = *reinterpret_cast<const uint64_t *>(s_lds + sh + o);
                 }
             }
         }
@@ -3074,85 +3010,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
     }
 }
 
-#else   // -DDBDE_MID_V1: one workgroup per group of frames, four dependent round trips (A/B against the pipelined form)
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void decode_mid_kernel(DecParams p) {
-    constexpr int NW = THREADS / 64;
-    __shared__ uint32_t s_tot[NW];
-    __shared__ uint32_t s_incl[THREADS];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t T = p.T, fpw = (uint32_t)THREADS / T;      // frames per workgroup
-    const uint32_t fl = tid / T, t = tid - fl * T;            // frame within the workgroup, tile within the frame
-    const uint32_t f = blockIdx.x * fpw + fl;
-    const bool active = fl < fpw && f < p.n_chunks;           // (n_chunks carries the frame count here)
-    const uint64_t need = 32ull + 2ull * T;
-    const uint64_t foff = active ? p.frame_offsets[f] : 0ull;
-    const bool in_range = active && in_extent(foff, need, p.stream_bytes);
-    const uint8_t *fb = p.stream + foff;
-    uint32_t d = 0, mn = 0;
-    if (in_range) { d = fb[24u + t]; mn = fb[28u + T + t]; }
-    // depth sum and "a depth above 8" count of every frame in one scan: low 20 bits words (<= 1024 * 255), above them flags
-    const uint32_t item = in_range ? (d | (d > 8u ? 1u << 20 : 0u)) : 0u;
-    uint32_t block_total;
-    const uint32_t incl = block_scan_incl<NW>(item, s_tot, (int)lane, (int)wave, block_total);
-    s_incl[tid] = incl;
-    __syncthreads();
-    if (!active) return;
-    const uint32_t first = fl * T;
-    const uint32_t base = first ? s_incl[first - 1u] : 0u;
-    const uint32_t upto = s_incl[first + T - 1u];
-    const uint32_t total = (upto - base) & 0xFFFFFu, n_bad = (upto - base) >> 20;
-    const uint32_t prefix = (incl - item - base) & 0xFFFFFu;  // payload words of the frame in front of this tile
-    bool ok = in_range;
-    if (ok) {
-        const int32_t nb = (int32_t)load_u32_bytes(fb + 20), nm = (int32_t)load_u32_bytes(fb + 24 + T);
-        const int32_t n64 = (int32_t)load_u32_bytes(fb + 28 + 2ull * T);
-        ok = nb == (int32_t)T && nm == (int32_t)T && n64 == (int32_t)total && n_bad == 0u &&
-             in_extent(foff, need + 8ull * total, p.stream_bytes);
-    }
-    if (t == 0u && p.results) {   // the frame's result record: dbde_unpack_frame's return value
-        uint32_t field = 0;
-        uint64_t index = 0, elapsed = 0;
-        if (in_extent(foff, 20, p.stream_bytes)) {
-            field = load_u32_bytes(fb);
-            index = load_u64_bytes(fb + 4);
-            elapsed = f64_to_u64_x86(__longlong_as_double((long long)load_u64_bytes(fb + 12)));
-        }
-        FrameResultDev *r = reinterpret_cast<FrameResultDev *>(p.results) + f;
-        r->u64s = (field == 2u && ok) ? 2u : 0xFFFFFFFFu;   // dbde_util.cpp:335,342
-        r->pad_ = 0;
-        r->index = index;
-        r->elapsed_ns = elapsed;
-        r->consumed = ok ? need + 8ull * total : 20ull;
-    }
-    if (!ok) return;   // rejected frame: image untouched (dbde_util.cpp:296-303)
-    const uint8_t *pay = fb + need + 8ull * prefix, *s_end = p.stream + p.stream_bytes;
-    const uint32_t mn4 = mn * 0x01010101u;
-    uint32_t v[16];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint64_t row = 0;
-        if (d != 0u) {
-            const uint8_t *q = pay + (uint32_t)r * d;
-            if (q + 8 <= s_end) row = load_u64_any(q);
-            else for (uint32_t b = 0; b < d; b++) row |= (uint64_t)q[b] << (8u * b);   // the stream's last bytes: nothing past the extent
-        }
-        uint32_t lo, hi;
-        expand_row(row, d, lo, hi);
-        v[2 * r] = add_bytes(lo, mn4);
-        v[2 * r + 1] = add_bytes(hi, mn4);
-    }
-    store_tile_generic(p.images + (size_t)f * p.frame_pixels, p.W, p.H, p.w, t, v);
-}
-
-#endif
-
 hipError_t launch_decode_mid(const DecParams &p, uint32_t n_frames, uint32_t n_cu, hipStream_t s) {
     DecParams q = p;
     q.n_chunks = n_frames;
     const uint32_t th = mid_decode_threads_for(p.T), per_wg = th / p.T;
     uint32_t groups = (n_frames + per_wg - 1u) / per_wg;
-#ifndef DBDE_MID_V1
     // 8-byte aligned image rows: pixels staged in LDS, aligned 16-byte stores (decode_mid_kernel<., true>)
     const bool staged = p.W % 8 == 0 && (reinterpret_cast<uintptr_t>(p.images) & 7u) == 0u && !DBDE_MID_NO_STAGE;
     auto go = [&](auto kernel, uint32_t threads) {
@@ -3173,12 +3035,6 @@ hipError_t launch_decode_mid(const DecParams &p, uint32_t n_frames, uint32_t n_c
         else if (th == 512u) go(decode_mid_kernel<512, false>, 512u);
         else go(decode_mid_kernel<1024, false>, 1024u);
     }
-#else
-    const dim3 grid(groups);
-    if (th == 256u) hipLaunchKernelGGL(decode_mid_kernel<256>, grid, dim3(256), 0, s, q);
-    else if (th == 512u) hipLaunchKernelGGL(decode_mid_kernel<512>, grid, dim3(512), 0, s, q);
-    else hipLaunchKernelGGL(decode_mid_kernel<1024>, grid, dim3(1024), 0, s, q);
-#endif
     return hipGetLastError();
 }
 
@@ -3558,14 +3414,6 @@ hipError_t launch_decode_frames(const DecParams &p, uint32_t n_frames, hipStream
     const dim3 grid((n_frames + per_wg - 1u) / per_wg);
     if (th == 256u) hipLaunchKernelGGL(decode_frames_kernel<256>, grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL(decode_frames_kernel<512>, grid, dim3(512), 0, s, q);
-    return hipGetLastError();
-}
-
-hipError_t launch_decode_tiny(const DecParams &p, uint32_t n_frames, hipStream_t s) {
-    DecParams q = p;
-    q.n_chunks = n_frames;
-    const uint32_t per_wg = 4u * (64u / p.T);
-    hipLaunchKernelGGL(decode_tiny_kernel, dim3((n_frames + per_wg - 1u) / per_wg), dim3(256), 0, s, q);
     return hipGetLastError();
 }
 

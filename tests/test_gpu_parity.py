@@ -859,9 +859,9 @@ def test_seeded_fuzz_against_oracle(codec, oracle):
 @pytest.mark.parametrize("W,H,n", [(8, 8, 1000), (64, 64, 300), (10, 10, 77), (33, 31, 50), (24, 16, 5), (1, 1, 9), (512, 8, 40),
                                    (7, 300, 33), (61, 59, 129)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
-def test_tiny_frames_many_per_wave(codec, codec_staged_decode, oracle, W, H, n, mode):
+def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, mode):
     """Frames of at most 64 tiles (the reference's randomized test is 1024 single-tile frames, dbde_util_test.cpp:66-96):
-    one tile per lane, several frames per wave in both directions (encode_tiny_kernel for slots, decode_tiny_kernel);
+    one tile per lane, several frames per wave in both directions (encode_tiny_kernel for slots, decode_mid_kernel: whole frames per 256-thread workgroup);
     every frame byte for byte against the oracle, both layouts, partial tiles, a frame count that leaves lanes idle."""
     import torch
     imgs = codec.synth_frames(mode, SEED, 50, n, W, H)
@@ -872,7 +872,8 @@ def test_tiny_frames_many_per_wave(codec, codec_staged_decode, oracle, W, H, n, 
         for f in range(n):
             assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
         total = int((offs[-1] + sizes[-1]).item())
-        for dec in (codec, codec_staged_decode):      # the default forms, and the staged whole-frame decoder where it applies
+        # (the default forms, the staged whole-frame decoder where it applies, three persistent workgroups walking their loop)
+        for dec in (codec, codec_staged_decode, codec_three_workgroups):
             canvas = torch.full_like(imgs, 0xEE)
             back, res = dec.decode_frames(buf, lead, total, offs, W, H, n, images=canvas)
             dec.sync()

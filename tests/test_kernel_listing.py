@@ -154,31 +154,35 @@ def test_no_scratch_and_expected_occupancy(listing):
                               "_ZN4dbde19encode_small_kernelILi1ELb1EEEvNS_9EncParamsE"]:
         enc = meta[name]
         assert enc["scratch"] == 0 and enc["vgpr"] <= 128 and enc["lds"] <= 80 * 1024, (name, enc)
-    dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi") or k.startswith("_ZN4dbde18decode_tiny_kernel")]
+    dec = [v for k, v in meta.items() if k.startswith("_ZN4dbde13decode_kernelILi")]
     assert dec and all(d["scratch"] == 0 and d["vgpr"] <= 96 and d["lds"] <= 40 * 1024 for d in dec), dec
+    # the small-frame decoder (256-thread instances are the ones launched): six persistent workgroups per CU
+    for staged in ("1", "0"):
+        mid = meta["_ZN4dbde17decode_mid_kernelILi256ELb%sEEEvNS_9DecParamsE" % staged]
+        assert mid["scratch"] == 0 and mid["vgpr"] <= 80 and mid["lds"] <= 24 * 1024, mid
 
 
-def test_decoder_uses_sdwa_field_expansion(listing):
-    """The decoder's field expansion is three SDWA shifts per four pixels: 96 in the general unpack of
-    each instance (two tiles x eight rows x six); a rewrite that silently falls back to mask / bfe / shift-or chains
-    shows here."""
-    body = "\n".join(function_body(listing, "_ZN4dbde13decode_kernelILi0ELi0ELi256EEEvNS_9DecParamsE"))
-    assert body.count("v_lshrrev_b32_sdwa") >= 96, body.count("v_lshrrev_b32_sdwa")
-
-
-def test_dbde16_kernels_do_not_spill():
-    """DBDE16: the encoder is built for four waves per SIMD (LDS allows four workgroups per CU) and must not spill; the
-    decoder stays LDS-bound."""
-    r = subprocess.run(["make", "-s", "-C", CSRC, "asm"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    text = open(os.path.join(CSRC, "dbde16_kernels.s")).read()
-    md = text[text.index("amdhsa.kernels:"):]
-    seen = {}
-    for entry in re.split(r"\n  - \.", md)[1:]:
-        get = lambda k: re.search(r"\.?%s:\s+(\S+)" % k, entry).group(1)
-        seen[get("name")] = (int(get("vgpr_count")), int(get("private_segment_fixed_size")), int(get("group_segment_fixed_size")))
-    enc = [v for k, v in seen.items() if "enc16_kernel" in k]
-    dec = [v for k, v in seen.items() if "dec16_kernel" in k]
-    assert enc and dec
-    assert all(v[0] <= 128 and v[1] == 0 and v[2] <= 40 * 1024 for v in enc), enc
-    assert all(v[0] <= 96 and v[1] == 0 and v[2] <= 40 * 1024 for v in dec), dec
+@pytest.mark.parametrize("mangled", ["_ZN4dbde17decode_mid_kernelILi256ELb1EEEvNS_9DecParamsE",
+                                     "_ZN4dbde17decode_mid_kernelILi256ELb0EEEvNS_9DecParamsE"])
+def test_small_frame_decoder_keeps_its_prefetch_in_flight(listing, mangled):
+    """decode_mid_kernel walks groups of frames in a software-pipelined loop: the depth / minimum bytes and the three I32
+    fields of the NEXT group and the offset of the one after it are requested at the top of an iteration and first
+    looked at behind the current group's payload loads.  Inside the loop: no vector-memory wait between those requests
+    and the scan's barrier (the scheduler once moved their consumers up to the loads; __syncthreads() would drain them
+    too), ONE wait behind the payload pieces, and none behind the last store of an iteration (a wait there would be a
+    wait for the stores)."""
+    lines = [ln.strip() for ln in function_body(listing, mangled)]
+    head = next(i for i, ln in enumerate(lines) if "Loop Header: Depth=1" in ln)
+    body = lines[head:]
+    ub = [i for i, ln in enumerate(body) if ln.startswith("global_load_ubyte")]
+    assert len(ub) >= 2, "the prefetch of the next group's depth / minimum bytes is gone"
+    bar = next(i for i, ln in enumerate(body) if ln.startswith("s_barrier") and i > ub[1])
+    assert not [ln for ln in body[ub[0]:bar] if re.match(r"s_waitcnt.*vmcnt", ln)], body[ub[0]:bar]
+    pieces = [i for i, ln in enumerate(body) if ln.startswith("global_load_dwordx4") and i > bar]
+    assert len(pieces) >= 4
+    first_wait = next(i for i, ln in enumerate(body) if re.match(r"s_waitcnt.*vmcnt", ln) and i > pieces[0])
+    assert first_wait > pieces[3] and "vmcnt(0)" in body[first_wait]
+    # the loop's latch (the block that falls into the header again, behind an iteration's stores) waits for nothing
+    latch = max(i for i in range(head) if lines[i].startswith(".LBB"))
+    assert "in Loop: Header=" in lines[latch], lines[latch]
+    assert not [ln for ln in lines[latch:head] if re.match(r"s_waitcnt.*vmcnt", ln)], lines[latch:head]

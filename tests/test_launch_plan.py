@@ -80,7 +80,7 @@ def test_unaligned_image_base_changes_the_form():
 
 
 @pytest.mark.parametrize("W,H,T,enc,dec,threads", [
-    (8, 8, 1, TINY, TINY, 256), (64, 64, 64, TINY, TINY, 256),
+    (8, 8, 1, TINY, MID, 256), (64, 64, 64, TINY, MID, 256),   # (decode: one kernel from single-tile frames up to 256 tiles)
     # 8-byte aligned rows, frames and buffers whole 16-byte blocks (round 4): whole frames per workgroup, staged through LDS
     # (encode; the decode side keeps decode_mid_kernel -- persistent, software-pipelined from the second half of round 4 --
     # up to 256 tiles and the chunk kernels above: the staged whole-frame decoder measured no faster and is an experiment switch)

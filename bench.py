@@ -727,7 +727,9 @@ def main():
                                             (1366, 768, 4096, "odd rows: any-geometry encoder, 192-thread staged decode"),
                                             (1440, 900, 2048, "16-byte rows, not whole cache lines: direct 16-byte stores"),
                                             (720, 1280, 4096, "16-byte rows, whole-tile-row chunks: direct or staged per chunk"),
-                                            (72, 72, 262144, "81 tiles: whole frames per workgroup (encode: staged through LDS, round 4)"),
+                                            (64, 64, 262144, "64 tiles: whole frames per wave (encode) / per 256-thread persistent workgroup (decode_mid_kernel, round 4)"),
+                                            (72, 72, 262144, "81 tiles: whole frames per workgroup (encode: staged through LDS; decode: persistent, software-pipelined, round 4)"),
+                                            (128, 128, 65536, "256 tiles: the largest frames of the small-frame decoder"),
                                             (160, 120, 65536, "300 tiles: three whole frames per 512-thread workgroup on the encode side (round 4)"),
                                             (320, 240, 16384, "1200 tiles: above the whole-frame forms, two chunks per frame")):
                     try:

@@ -2794,6 +2794,9 @@ struct MidMeta {
     uint32_t nb, nm, n64;     // the frame's three I32 fields (every lane of a frame asks for the same words)
 };
 
+#ifndef DBDE_MID_NT
+#define DBDE_MID_NT DBDE_NT   // A/B switch: the staged image leaves with non-temporal stores
+#endif
 #ifndef DBDE_MID_NO_STAGE
 #define DBDE_MID_NO_STAGE 0   // A/B switch: 1 = tile rows stored straight from the registers at every width
 #endif
@@ -2983,7 +2986,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
                     const bool upper_only = j == 0u && sh != 0u, lower_only = 16u * j + 16u > sh + nbytes;
                     if (!upper_only && !lower_only) {
                         const u32x4_t q = *reinterpret_cast<const u32x4_t *>(s_lds + 16u * j);
-                        if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(dst));
+#ifdef DBDE_MID_ABLATE_STORES
+                        if (q[0] != 0x12345678u || q[3] != 0x9ABCDEF1u) continue;
+#endif
+                        if (DBDE_MID_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(dst));
                         else *reinterpret_cast<u32x4_t *>(dst) = q;
                     } else if (!(upper_only && lower_only)) {
                         const uint32_t o = upper_only ? 8u : 0u;

@@ -58,7 +58,9 @@ BIG = [  # BASELINE.json configs 2, 3, 4 at the bench seeds: hashes only
     ("shape_1080x1920", 1920, 1080), ("shape_1366x768", 768, 1366), ("shape_1440x900", 900, 1440),
     ("shape_720x1280", 1280, 720), ("shape_72x72", 72, 72), ("shape_96x96", 96, 96),
     # frames of 300 .. 1200 tiles (round 4: whole frames per workgroup up to ~700 tiles, staged loads and stores)
-    ("shape_160x120", 120, 160), ("shape_176x144", 144, 176), ("shape_320x240", 240, 320)]
+    ("shape_160x120", 120, 160), ("shape_176x144", 144, 176), ("shape_320x240", 240, 320),
+    # frames of 64 and 256 tiles: the two ends of the small-frame decoder's old and new ranges (round 4, second half)
+    ("shape_64x64", 64, 64), ("shape_128x128", 128, 128)]
 # bench.py --gpus N: rank r round-trips frames r * 1024 .. r * 1024 + 1023 of the headline shape; every rank is held to
 # the reference's SHA-256 of ITS frames 0 and 3 (rank 0's are the cfg2 entries above)
 RANK_FRAMES = [r * 1024 + d for r in range(1, 8) for d in (0, 3)]

@@ -487,7 +487,7 @@ def test_uniform_depth_content(codec, oracle, d):
 
 @pytest.mark.parametrize("name", ["cfg2_4096x3072", "cfg3_2048x2048", "cfg4_1921x1081", "shape_1080x1920", "shape_1366x768",
                                   "shape_1440x900", "shape_720x1280", "shape_72x72", "shape_96x96",
-                                  "shape_160x120", "shape_176x144", "shape_320x240", "cfg2_rank_frames"])
+                                  "shape_160x120", "shape_176x144", "shape_320x240", "shape_64x64", "shape_128x128", "cfg2_rank_frames"])
 def test_baseline_configs_full_size(codec, golden, name):
     """BASELINE.json configs 2-4 and the shapes whose kernel forms differ from theirs (portrait HD, 1366x768, 16-byte
     rows that are not whole cache lines, frames of 81 / 144 tiles): packed-frame hashes equal the REAL reference's

@@ -443,6 +443,9 @@ struct EncPlan {
 #define DBDE_FRAMES_DECODE_TILES 640
 #endif
 // rows 8-byte aligned, frames and base whole 16-byte blocks: what the staged whole-frame kernels take
+#ifndef DBDE_GROUP_ENCODE_TILES
+#define DBDE_GROUP_ENCODE_TILES 85    // largest frame (tiles) of the persistent small-frame encoder where frames above 64 tiles fill 90 % of its lanes (77 .. 85 tiles: three frames)
+#endif
 static bool frames_geometry(const Geometry &g, int W, uintptr_t images) {
     return W % 8 == 0 && g.pixels % 16 == 0 && (images & 15u) == 0 && g.T > 64u;
 }
@@ -493,7 +496,20 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
     pl.n_chunks64 = (uint64_t)n_frames * pl.enc_cpf;
     pl.aligned_out = ((out & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
     pl.kernel = 0;
-    if (g.T <= 64u && slot_stride != 0) pl.kernel = 2;          // tiny frames in slots: several frames per wave, nothing shared
+    const bool blocks16 = W % 8 == 0 && g.pixels % 16 == 0 && (images & 15u) == 0 && (out & 15u) == 0 && slot_stride % 16 == 0;
+    if (false) {}
+#ifndef DBDE_NO_GROUP
+    // Small frames in slots, 8-byte aligned rows, frames and buffers whole 16-byte blocks: persistent workgroups, the next
+    // group's pixels in flight while a group is encoded (encode_group_kernel: one tile per lane, 256 / T frames per
+    // workgroup).  Measured against what it replaces (mixed / incompressible): 64x64 0.40 -> 0.53 / 0.33 -> 0.56, 32x32 0.35
+    // -> 0.49 / 0.32 -> 0.47, 40x24 0.31 -> 0.46 / 0.30 -> 0.41; 72x72 (81 tiles, three frames fill 95 % of the lanes) 0.49 ->
+    // 0.50 / 0.49 -> 0.56.  Where whole frames leave lanes empty the two-tiles-per-lane kernel below keeps mixed content
+    // (96x96, one frame of 144 tiles per workgroup: 0.51 -> 0.42; 128x128 at full fill 0.62 -> 0.56, incompressible 0.54 ->
+    // 0.58), and single-tile frames keep the per-wave kernel (8x8: 0.17 -> 0.09, 256 frame images per workgroup).
+    else if (slot_stride != 0 && blocks16 && g.T >= 4u &&
+             (g.T <= 64u || (g.T <= (unsigned)DBDE_GROUP_ENCODE_TILES && (256u / g.T) * g.T * 10u >= 256u * 9u))) pl.kernel = 5;
+#endif
+    else if (g.T <= 64u && slot_stride != 0) pl.kernel = 2;     // tiny frames in slots: several frames per wave, nothing shared
 #ifndef DBDE_NO_FRAMES
     else if (slot_stride != 0 && g.T <= (unsigned)DBDE_FRAMES_ENCODE_TILES && frames_geometry(g, W, images) && (out & 15u) == 0 &&
              slot_stride % 16 == 0) pl.kernel = 4;              // 65 .. 700 tiles, aligned rows: whole frames per workgroup, staged
@@ -544,6 +560,13 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
     p.seg_q = pl.seg_q;
     p.seg_rem = pl.seg_rem;
     p.magic_seg = pl.seg_per_row ? div_magic_of(pl.seg_per_row) : 0u;
+
+    if (pl.kernel == 5) {   // 1 .. 256 tiles in slots, aligned rows: persistent workgroups, pixels double-buffered (encode_group_kernel)
+        span_begin(ctx, 0);
+        HIP_TRY(ctx, launch_encode_group(p, (uint32_t)n_frames, (ctx->exp_flags & 1024u) ? 0u : (uint32_t)ctx->n_cu, ctx->stream));   // (experiment bit 10: three workgroups)
+        span_end(ctx);
+        return DBDE_HIP_OK;
+    }
 
     if (pl.kernel == 2) {   // tiny frames in slots: several frames per wave, nothing shared (encode_tiny_kernel)
         span_begin(ctx, 0);
@@ -901,7 +924,7 @@ int dbde_hip_encode_plan(int W, int H, int n_frames, uint64_t image_address, uin
     plan->kernel = pl.kernel;
     plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? (pl.seg_per_row ? 4 : pl.pairs_per_wave == 63u ? 3 : 1) : 2);
     plan->aligned_out = pl.aligned_out ? 1 : 0;
-    plan->threads = pl.kernel == 2 ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u)));
+    plan->threads = (pl.kernel == 2 || pl.kernel == 5) ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u)));
     plan->chunks_per_frame = pl.kernel >= 2 ? 0u : pl.enc_cpf;
     plan->chunk_tiles = pl.kernel >= 2 ? 0u : (pl.seg_per_row ? 2u * (pl.seg_q + (pl.seg_rem ? 1u : 0u)) * (kEncChunkTiles / 128u) : pl.lanes_per_row ? 2u * pl.pairs_per_wave * (kEncChunkTiles / 128u) : kEncChunkTiles);
     plan->n_chunks = pl.kernel >= 2 ? 0ull : pl.n_chunks64;

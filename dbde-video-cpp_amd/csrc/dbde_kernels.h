@@ -179,6 +179,9 @@ hipError_t launch_decode_mid(const struct DecParams &p, uint32_t n_frames, uint3
 hipError_t launch_encode_frames(const EncParams &p, uint32_t n_frames, hipStream_t s);
 hipError_t launch_decode_frames(const struct DecParams &p, uint32_t n_frames, hipStream_t s);
 uint32_t frames_threads_for(uint32_t T);
+// Frames of 1 .. 256 tiles with 8-byte aligned rows, one slot per frame: one tile per lane, persistent 256-thread workgroups,
+// the next group's pixels in flight (LDS-DMA into the other of two buffers) while a group is encoded (n_cu = 0: three workgroups, tests)
+hipError_t launch_encode_group(const EncParams &p, uint32_t n_frames, uint32_t n_cu, hipStream_t s);
 // Frames of at most 64 tiles, one slot per frame: one tile per lane, 64 / T frames per wave, no workspace.
 hipError_t launch_encode_tiny(const EncParams &p, uint32_t n_frames, hipStream_t s);
 hipError_t launch_decode_index(const IdxParams &p, int n_frames, hipStream_t s);

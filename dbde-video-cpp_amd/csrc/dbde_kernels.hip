@@ -3214,6 +3214,187 @@ __global__ __launch_bounds__(THREADS) void encode_frames_kernel(EncParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// ENCODE, small frames in slots, 8-byte aligned rows, 1 .. 256 tiles: persistent workgroups, pixels double-buffered (round 4)
+// ---------------------------------------------------------------------------------------
+// What the decode side gained from walking groups of frames in a software-pipelined loop (decode_mid_kernel), mirrored:
+// a lane owns ONE tile, a 256-thread workgroup as many whole frames as fit (256 / T), and the workgroup is persistent.
+// The pixels of a group are one contiguous byte range (frames follow each other in the batch) whose address is plain
+// arithmetic, so the range of the NEXT group is requested by LDS-DMA into the other of two pixel buffers at the top of an
+// iteration and has a whole iteration to arrive: no wave ever waits for a pixel except in the launch's first step.
+// Tiles are cut out of the image with aligned 8-byte LDS reads, offsets are a segmented scan (DPP + wave totals), the
+// payload words go where the pixels were (the scan's barrier says every tile has been cut), header, fields, depth and
+// minimum bytes into a small image of the frame's first 32 + 2T bytes, and every frame leaves as aligned 16-byte blocks
+// -- the lanes of a frame store ITS blocks, all frames of the group at once (encode_frames_kernel walks the frames one
+// after the other with the whole workgroup: most lanes idle on frames of a few hundred bytes).
+// One slot per frame (nothing is shared between frames: no workspace, nothing to wait for).
+constexpr uint32_t kGroupThreads = 256u;
+
+// 16 bytes at offset o of a frame whose first `meta` = 32 + 2T bytes lie at m and whose payload words lie 8-byte aligned at
+// LDS byte address pay0 (pay: the same place as a pointer): whole blocks of the fields' image as they are; payload blocks
+// as five aligned dwords shifted into place; the one block that holds the end of the minimum array byte by byte.
+__device__ __forceinline__ u32x4_t frame_block(const uint8_t *m, uint32_t pay0, const uint8_t *pay, uint32_t meta, uint32_t o) {
+    u32x4_t q;
+    if (o + 16u <= meta) {
+        q = *reinterpret_cast<const u32x4_t *>(m + o);
+    } else {
+        const int po = (int)o - (int)meta;                  // may be negative in the straddling block
+        const uint32_t a = (uint32_t)((int)pay0 + po), a4 = a & ~3u;
+        uint64_t d01, d23;
+        uint32_t d4;
+        asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(d01), "=&v"(d23), "=&v"(d4) : "v"(po < 0 ? pay0 & ~3u : a4) : "memory");
+        const uint32_t w0 = (uint32_t)d01, w1 = (uint32_t)(d01 >> 32), w2 = (uint32_t)d23, w3 = (uint32_t)(d23 >> 32);
+        q[0] = __builtin_amdgcn_alignbyte(w1, w0, a);
+        q[1] = __builtin_amdgcn_alignbyte(w2, w1, a);
+        q[2] = __builtin_amdgcn_alignbyte(w3, w2, a);
+        q[3] = __builtin_amdgcn_alignbyte(d4, w3, a);
+        if (po < 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) {
+                uint32_t x = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t at = o + 4u * i + j;
+                    x |= (uint32_t)(at < meta ? m[at] : pay[at - meta]) << (8u * j);
+                }
+                q[i] = x;
+            }
+        }
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(kGroupThreads, 4) void encode_group_kernel(EncParams p) {
+    constexpr uint32_t TH = kGroupThreads, NW = TH / 64u, kWords = TH * 8u;       // 8 payload words (64 pixels) per tile slot
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_meta[];               // (256 / T) x the frame's first 32 + 2T bytes, rounded up to 16
+    __shared__ __attribute__((aligned(16))) uint64_t s_buf[2][kWords + 64u];      // a group's pixels, later its payload words (+ a trash word per lane of a wave)
+    __shared__ uint32_t s_tot[NW];
+    __shared__ uint32_t s_incl[TH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t T = p.T, fpw = TH / T;
+    const uint32_t fl = tid / T, t = tid - fl * T;
+    const uint32_t n_frames = p.n_chunks, n_groups = (n_frames + fpw - 1u) / fpw, G = gridDim.x;   // (n_chunks carries the frame count here)
+    const uint32_t first = fl < fpw ? fl * T : 0u;
+    const uint32_t P = (uint32_t)p.frame_pixels, W = (uint32_t)p.W;
+    const uint32_t meta = 32u + 2u * T, mpitch = (meta + 15u) & ~15u;
+    uint32_t tx;
+    const uint32_t ty = div_magic(t, p.w, p.magic_w, tx);
+    const uint32_t px = (fl < fpw ? fl * P : 0u) + 8u * tx;
+
+    auto fetch = [&](uint32_t g, uint32_t b) {   // the pixels of group g -> buffer b, whole 16-byte blocks, nothing waited for
+        if (g >= n_groups) return;
+        const uint32_t nfr = n_frames - g * fpw < fpw ? n_frames - g * fpw : fpw;
+        const uint8_t *src = p.images + (size_t)(g * fpw) * P;
+        const uint32_t n16 = nfr * (P >> 4);
+        for (uint32_t i = tid; i < n16; i += TH)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16ull * i),
+                                             (__attribute__((address_space(3))) void *)(&s_buf[b][2u * (i - lane)]), 16, 0, DBDE_NT ? 2 : 0);
+    };
+    auto pref = [&](uint32_t x) -> uint32_t {    // inclusive prefix of the depths over the workgroup at lane x
+        uint32_t a = s_incl[x];
+#pragma unroll
+        for (uint32_t k = 0; k + 1u < NW; k++) a += k < (x >> 6) ? s_tot[k] : 0u;
+        return a;
+    };
+
+    uint32_t g = blockIdx.x, cur = 0;
+    fetch(g, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a barrier does not drain vector memory)
+    lds_barrier();
+    for (; g < n_groups; g += G, cur ^= 1u) {
+        fetch(g + G, cur ^ 1u);                  // in flight until this group's frames are ready to leave
+        const uint32_t nfr = n_frames - g * fpw < fpw ? n_frames - g * fpw : fpw;
+        const bool active = fl < nfr;
+        const uint32_t f = g * fpw + fl;
+        // ---- the lane's tile, cut out of the image (rows are 8-byte aligned; rows below the image repeat its last one) ----
+        uint32_t v[16];
+        {
+            const uint8_t *img = reinterpret_cast<const uint8_t *>(s_buf[cur]);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint32_t yy = 8u * ty + (uint32_t)r;
+                yy = yy < (uint32_t)p.H ? yy : (uint32_t)p.H - 1u;
+                const uint2 q = *reinterpret_cast<const uint2 *>(img + px + yy * W);
+                v[2 * r] = q.x; v[2 * r + 1] = q.y;
+            }
+        }
+        uint32_t mn, mx;
+        tile_minmax(v, mn, mx);
+        const uint32_t d = active ? depth_of_range(mx - mn) : 0u;
+        const uint32_t w_incl = wave_scan_incl(d);
+        s_incl[tid] = w_incl;
+        if (lane == 63u) s_tot[wave] = w_incl;
+        lds_barrier();                           // (also: every tile is in registers, the image may be written over)
+        const uint32_t base = first ? pref(active ? first - 1u : 0u) : 0u;
+        const uint32_t n64 = pref(active ? first + T - 1u : 0u) - base;
+        const uint32_t prefix = pref(tid) - d - base;
+        // ---- payload words into the frame's 8-byte aligned area; depth / minimum bytes and the fields where they lie ----
+        if (active) {
+            pack_tile(v, mn, d, s_buf[cur], fl * 8u * T + prefix, kWords + lane);
+            uint8_t *m = s_meta + fl * mpitch;
+            m[24u + t] = (uint8_t)d;
+            m[28u + T + t] = (uint8_t)mn;
+            if (t == 0u) {   // header + the three I32 fields (dbde_util.cpp:140-146, 182-196); trap T1: F64 on the wire
+                const uint64_t index = p.indices ? p.indices[f] : p.first_index + f;
+                const uint64_t el = p.elapsed_ns ? p.elapsed_ns[f] : 0ull;
+                const uint64_t elbits = (uint64_t)__double_as_longlong(__ull2double_rn(el));
+                uint32_t *h = reinterpret_cast<uint32_t *>(m);      // (the frame's image starts 16-byte aligned)
+                h[0] = 2u; h[1] = (uint32_t)index; h[2] = (uint32_t)(index >> 32);
+                h[3] = (uint32_t)elbits; h[4] = (uint32_t)(elbits >> 32); h[5] = T;
+                store_u32_bytes(m + 24u + T, T);
+                store_u32_bytes(m + 28u + 2u * T, n64);
+                if (p.frame_offsets) p.frame_offsets[f] = (uint64_t)f * p.slot_stride;
+                if (p.frame_bytes) p.frame_bytes[f] = (uint64_t)meta + 8ull * n64;
+            }
+        }
+        lds_barrier();
+        // The next group's pixels were asked for an iteration ago: waited for HERE, in front of this group's stores (loads and
+        // stores share the counter: behind the stores it would be a wait for them too).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- every frame leaves as aligned 16-byte blocks, exactly its 32 + 2T + 8 n64 bytes, stored by its own lanes ----
+        if (active) {
+            const uint32_t len = meta + 8u * n64, n_blocks = (len + 15u) >> 4;
+            uint8_t *out = p.out + (uint64_t)f * p.slot_stride;
+            const uint8_t *m = s_meta + fl * mpitch;
+            const uint8_t *pay = reinterpret_cast<const uint8_t *>(s_buf[cur]) + fl * 64u * T;
+            const uint32_t pay0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)pay;
+            for (uint32_t b = t; b < n_blocks; b += T) {
+                const uint32_t o = 16u * b;
+                const u32x4_t q = frame_block(m, pay0, pay, meta, o);
+                uint8_t *dst = out + o;
+                if (o + 16u <= len) {
+                    if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(dst));
+                    else *reinterpret_cast<u32x4_t *>(dst) = q;
+                } else {   // the frame's last, partial block: its bytes and nothing behind them (lengths are even)
+                    const uint32_t n = len - o;
+                    uint64_t lo = ((uint64_t)q[1] << 32) | q[0];
+                    const uint64_t hi = ((uint64_t)q[3] << 32) | q[2];
+                    if (n & 8u) { *reinterpret_cast<uint64_t *>(dst) = lo; dst += 8; lo = hi; }
+                    if (n & 4u) { *reinterpret_cast<uint32_t *>(dst) = (uint32_t)lo; dst += 4; lo >>= 32; }
+                    if (n & 2u) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)lo;
+                }
+            }
+        }
+        lds_barrier();   // the frames have left: both images may be written again; every wave's share of the next pixels has landed
+    }
+}
+
+hipError_t launch_encode_group(const EncParams &p, uint32_t n_frames, uint32_t n_cu, hipStream_t s) {
+    EncParams q = p;
+    q.n_chunks = n_frames;
+    q.chunks_per_frame = 1u;
+    const uint32_t fpw = kGroupThreads / p.T;
+    const uint32_t meta_bytes = fpw * ((32u + 2u * p.T + 15u) & ~15u);
+    const uint32_t groups = (n_frames + fpw - 1u) / fpw;
+    // persistent: as many workgroups as the device holds (n_cu = 0, tests: three, so that small batches walk the loop too)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, encode_group_kernel, (int)kGroupThreads, meta_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint32_t resident = n_cu ? n_cu * (uint32_t)per_cu : 3u;
+    hipLaunchKernelGGL(encode_group_kernel, dim3(groups < resident ? groups : resident), dim3(kGroupThreads), meta_bytes, s, q);
+    return hipGetLastError();
+}
+
 // Threads of the workgroup (256: 512 tile slots, 512: 1024) whole frames of T tiles fill best.
 uint32_t frames_threads_for(uint32_t T) {
     if (T > 512u) return 512u;

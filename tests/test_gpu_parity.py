@@ -857,7 +857,10 @@ def test_seeded_fuzz_against_oracle(codec, oracle):
 
 
 @pytest.mark.parametrize("W,H,n", [(8, 8, 1000), (64, 64, 300), (10, 10, 77), (33, 31, 50), (24, 16, 5), (1, 1, 9), (512, 8, 40),
-                                   (7, 300, 33), (61, 59, 129)])
+                                   (7, 300, 33), (61, 59, 129),
+                                   # round 4, the persistent small-frame encoder (8-byte rows, frames whole 16-byte blocks): 16, 15
+                                   # (rows below the image repeated) and 4 tiles a frame, a last group that is part empty
+                                   (32, 32, 333), (40, 20, 100), (16, 16, 1000)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
 def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, mode):
     """Frames of at most 64 tiles (the reference's randomized test is 1024 single-tile frames, dbde_util_test.cpp:66-96):
@@ -871,6 +874,10 @@ def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workg
         frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=50, slot_stride=slot)
         for f in range(n):
             assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
+        if slot == slot_bytes:   # the persistent small-frame encoder on three workgroups: its double-buffered loop many times over
+            frames3, _ = gpu_encode(codec_three_workgroups, imgs, W, H, n, first_index=50, slot_stride=slot)
+            for f in range(n):
+                assert frames3[f].tobytes() == frames[f].tobytes(), (W, H, mode, "three workgroups", f)
         total = int((offs[-1] + sizes[-1]).item())
         # (the default forms, the staged whole-frame decoder where it applies, three persistent workgroups walking their loop)
         for dec in (codec, codec_staged_decode, codec_three_workgroups):
@@ -900,6 +907,10 @@ def test_mid_frames_many_per_workgroup(codec, codec_staged_decode, codec_three_w
         frames, (buf, lead, offs, sizes) = gpu_encode(codec, imgs, W, H, n, first_index=50, slot_stride=slot)
         for f in range(n):
             assert frames[f].tobytes() == oracle.pack_frame(50 + f, imgs_h[f], W, H).tobytes(), (W, H, mode, slot, f)
+        if slot == slot_bytes:   # the persistent small-frame encoder on three workgroups: its double-buffered loop many times over
+            frames3, _ = gpu_encode(codec_three_workgroups, imgs, W, H, n, first_index=50, slot_stride=slot)
+            for f in range(n):
+                assert frames3[f].tobytes() == frames[f].tobytes(), (W, H, mode, "three workgroups", f)
         total = int((offs[-1] + sizes[-1]).item())
         # the default forms, the staged whole-frame decoder where it applies, and decode_mid_kernel on three persistent
         # workgroups: every workgroup walks its software-pipelined loop several times (metadata of the next group and the

@@ -11,7 +11,7 @@ def built():
     dv.build()
 
 
-PERSISTENT, SMALL, TINY, MID, FRAMES = 0, 1, 2, 3, 4
+PERSISTENT, SMALL, TINY, MID, FRAMES, GROUP = 0, 1, 2, 3, 4, 5
 DIRECT, STAGED, TILES = 0, 1, 2
 TABLE, SELF, FUSED = 0, 1, 2
 
@@ -80,11 +80,12 @@ def test_unaligned_image_base_changes_the_form():
 
 
 @pytest.mark.parametrize("W,H,T,enc,dec,threads", [
-    (8, 8, 1, TINY, MID, 256), (64, 64, 64, TINY, MID, 256),   # (decode: one kernel from single-tile frames up to 256 tiles)
+    (8, 8, 1, TINY, MID, 256), (64, 64, 64, GROUP, MID, 256),   # (decode: one kernel from single-tile frames up to 256 tiles)
+    (32, 32, 16, GROUP, MID, 256), (16, 16, 4, GROUP, MID, 256), (16, 8, 2, TINY, MID, 256), (20, 20, 9, TINY, MID, 256),
     # 8-byte aligned rows, frames and buffers whole 16-byte blocks (round 4): whole frames per workgroup, staged through LDS
     # (encode; the decode side keeps decode_mid_kernel -- persistent, software-pipelined from the second half of round 4 --
     # up to 256 tiles and the chunk kernels above: the staged whole-frame decoder measured no faster and is an experiment switch)
-    (72, 72, 81, FRAMES, MID, 256),          # 6 frames in 512 tile slots (95 %)
+    (72, 72, 81, GROUP, MID, 256),           # three frames per 256-thread persistent workgroup (95 %)
     (96, 96, 144, FRAMES, MID, 512),         # 7 frames in 1024 slots (98 %; 3 in 512: 84 %)
     (128, 128, 256, FRAMES, MID, 256),       # 2 frames in 512 slots
     (160, 120, 300, FRAMES, 0, 512),         # 3 frames in 1024 slots (88 %; one in 512: 59 %)
@@ -98,13 +99,13 @@ def test_small_frames(W, H, T, enc, dec, threads):
     e = dv.encode_plan(W, H, 100000, slot_stride=slot)
     d = dv.decode_plan(W, H, 100000)
     assert e["kernel"] == enc and d["kernel"] == dec, (e, d)
-    if enc in (TINY, MID, FRAMES):
+    if enc in (TINY, MID, FRAMES, GROUP):
         assert e["threads"] == threads
     if dec == MID:
         assert d["threads"] == 256          # the persistent mid decoder: 256-thread workgroups at every fill
     # an image base that is not a multiple of 16 bytes: the staged form does not apply
-    if enc == FRAMES:
-        assert dv.encode_plan(W, H, 100000, slot_stride=slot, image_address=8)["kernel"] in (MID, PERSISTENT)
+    if enc in (FRAMES, GROUP):
+        assert dv.encode_plan(W, H, 100000, slot_stride=slot, image_address=8)["kernel"] in (TINY, MID, PERSISTENT)
         assert dv.decode_plan(W, H, 100000, image_address=8)["kernel"] in (MID, 0)
     # concatenated frames need each other's sizes: the chunk kernels
     assert dv.encode_plan(W, H, 100000, slot_stride=0)["kernel"] in (PERSISTENT, SMALL)

@@ -3060,6 +3060,41 @@ hipError_t launch_decode_mid(const DecParams &p, uint32_t n_frames, uint32_t n_c
 //     does); the decoder lands the frame's bytes where LDS and global addresses agree mod 16 and unpacks from there.
 // One slot per frame on the encode side (nothing is shared between frames: no workspace, nothing to wait for); the decoder
 // takes any frame offsets.  Validation is the reference's (dbde_util.cpp:295-303) plus depth <= 8 and the readable extent.
+// 16 bytes at offset o of a frame whose first `meta` = 32 + 2T bytes lie at m and whose payload words lie 8-byte aligned at
+// LDS byte address pay0 (pay: the same place as a pointer): whole blocks of the fields' image as they are; payload blocks
+// as five aligned dwords shifted into place; the one block that holds the end of the minimum array byte by byte.
+__device__ __forceinline__ u32x4_t frame_block(const uint8_t *m, uint32_t pay0, const uint8_t *pay, uint32_t meta, uint32_t o) {
+    u32x4_t q;
+    if (o + 16u <= meta) {
+        q = *reinterpret_cast<const u32x4_t *>(m + o);
+    } else {
+        const int po = (int)o - (int)meta;                  // may be negative in the straddling block
+        const uint32_t a = (uint32_t)((int)pay0 + po), a4 = a & ~3u;
+        uint64_t d01, d23;
+        uint32_t d4;
+        asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(d01), "=&v"(d23), "=&v"(d4) : "v"(po < 0 ? pay0 & ~3u : a4) : "memory");
+        const uint32_t w0 = (uint32_t)d01, w1 = (uint32_t)(d01 >> 32), w2 = (uint32_t)d23, w3 = (uint32_t)(d23 >> 32);
+        q[0] = __builtin_amdgcn_alignbyte(w1, w0, a);
+        q[1] = __builtin_amdgcn_alignbyte(w2, w1, a);
+        q[2] = __builtin_amdgcn_alignbyte(w3, w2, a);
+        q[3] = __builtin_amdgcn_alignbyte(d4, w3, a);
+        if (po < 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) {
+                uint32_t x = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t at = o + 4u * i + j;
+                    x |= (uint32_t)(at < meta ? m[at] : pay[at - meta]) << (8u * j);
+                }
+                q[i] = x;
+            }
+        }
+    }
+    return q;
+}
+
 template <int THREADS>
 struct FramesLds {
     static constexpr uint32_t kCap = 2u * THREADS;                 // tile slots
@@ -3165,39 +3200,10 @@ __global__ __launch_bounds__(THREADS) void encode_frames_kernel(EncParams p) {
         uint8_t *out = p.out + (uint64_t)(f0 + g) * p.slot_stride;
         const uint8_t *m = s_meta + g * mpitch;
         const uint32_t pay0 = lds_pay + g * 64u * T;                 // LDS byte address of the frame's payload
+        const uint8_t *pay = reinterpret_cast<const uint8_t *>(s_px) + g * 64u * T;
         for (uint32_t b = tid; b < n_blocks; b += THREADS) {
             const uint32_t o = 16u * b;
-            u32x4_t q;
-            if (o + 16u <= meta) {
-                q = *reinterpret_cast<const u32x4_t *>(m + o);
-            } else {
-                // payload bytes [o - meta, o - meta + 16): five aligned dwords around them, shifted into place (a block that
-                // also holds the end of the minimum array -- one per frame -- takes those bytes from the fields' image)
-                const int po = (int)o - (int)meta;                  // may be negative in the straddling block
-                const uint32_t a = (uint32_t)((int)pay0 + po), a4 = a & ~3u;
-                uint64_t d01, d23;
-                uint32_t d4;
-                asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(d01), "=&v"(d23), "=&v"(d4) : "v"(po < 0 ? pay0 & ~3u : a4) : "memory");
-                const uint32_t w0 = (uint32_t)d01, w1 = (uint32_t)(d01 >> 32), w2 = (uint32_t)d23, w3 = (uint32_t)(d23 >> 32);
-                q[0] = __builtin_amdgcn_alignbyte(w1, w0, a);
-                q[1] = __builtin_amdgcn_alignbyte(w2, w1, a);
-                q[2] = __builtin_amdgcn_alignbyte(w3, w2, a);
-                q[3] = __builtin_amdgcn_alignbyte(d4, w3, a);
-                if (po < 0) {   // the straddling block, byte by byte
-                    const uint8_t *pay = reinterpret_cast<const uint8_t *>(s_px) + g * 64u * T;
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; i++) {
-                        uint32_t x = 0;
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++) {
-                            const uint32_t at = o + 4u * i + j;
-                            x |= (uint32_t)(at < meta ? m[at] : pay[at - meta]) << (8u * j);
-                        }
-                        q[i] = x;
-                    }
-                }
-            }
+            const u32x4_t q = frame_block(m, pay0, pay, meta, o);
             uint8_t *dst = out + o;
             if (o + 16u <= len) {
                 if (DBDE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(dst));
@@ -3229,41 +3235,6 @@ __global__ __launch_bounds__(THREADS) void encode_frames_kernel(EncParams p) {
 // after the other with the whole workgroup: most lanes idle on frames of a few hundred bytes).
 // One slot per frame (nothing is shared between frames: no workspace, nothing to wait for).
 constexpr uint32_t kGroupThreads = 256u;
-
-// 16 bytes at offset o of a frame whose first `meta` = 32 + 2T bytes lie at m and whose payload words lie 8-byte aligned at
-// LDS byte address pay0 (pay: the same place as a pointer): whole blocks of the fields' image as they are; payload blocks
-// as five aligned dwords shifted into place; the one block that holds the end of the minimum array byte by byte.
-__device__ __forceinline__ u32x4_t frame_block(const uint8_t *m, uint32_t pay0, const uint8_t *pay, uint32_t meta, uint32_t o) {
-    u32x4_t q;
-    if (o + 16u <= meta) {
-        q = *reinterpret_cast<const u32x4_t *>(m + o);
-    } else {
-        const int po = (int)o - (int)meta;                  // may be negative in the straddling block
-        const uint32_t a = (uint32_t)((int)pay0 + po), a4 = a & ~3u;
-        uint64_t d01, d23;
-        uint32_t d4;
-        asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(d01), "=&v"(d23), "=&v"(d4) : "v"(po < 0 ? pay0 & ~3u : a4) : "memory");
-        const uint32_t w0 = (uint32_t)d01, w1 = (uint32_t)(d01 >> 32), w2 = (uint32_t)d23, w3 = (uint32_t)(d23 >> 32);
-        q[0] = __builtin_amdgcn_alignbyte(w1, w0, a);
-        q[1] = __builtin_amdgcn_alignbyte(w2, w1, a);
-        q[2] = __builtin_amdgcn_alignbyte(w3, w2, a);
-        q[3] = __builtin_amdgcn_alignbyte(d4, w3, a);
-        if (po < 0) {
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; i++) {
-                uint32_t x = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    const uint32_t at = o + 4u * i + j;
-                    x |= (uint32_t)(at < meta ? m[at] : pay[at - meta]) << (8u * j);
-                }
-                q[i] = x;
-            }
-        }
-    }
-    return q;
-}
 
 __global__ __launch_bounds__(kGroupThreads, 4) void encode_group_kernel(EncParams p) {
     constexpr uint32_t TH = kGroupThreads, NW = TH / 64u, kWords = TH * 8u;       // 8 payload words (64 pixels) per tile slot

@@ -26,9 +26,12 @@ for log in sorted(glob.glob(os.path.join(d, "*.log"))):
         t = [x[1] for x in sorted(v)]
         timed = t[2:] if len(t) > 4 else t
         avg = sum(timed) / len(timed)
-        main = any(s in k for s in ("encode_kernel", "decode_kernel", "encode_mid", "decode_mid", "encode_small", "encode_tiny", "decode_tiny"))
+        main = any(s in k for s in ("encode_kernel", "decode_kernel", "encode_mid", "decode_mid", "encode_small", "encode_tiny", "decode_tiny",
+                                    "encode_group", "encode_frames", "decode_frames"))
         frac = f"{alg / (avg * 1e-9) / 8e12:.3f}" if main else "-"
         out.append(f"   {k.split('(')[0][-70:]:70s} x{len(t):3d}  avg {avg/1e3:9.1f} us  min {min(t)/1e3:9.1f}  frac {frac}")
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r03_shapes_summary.txt")
+# (the directory's name says which round: prof_r03_shapes -> r03_shapes_summary.txt)
+name = os.path.basename(d).replace("prof_", "") + "_summary.txt"
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
 open(path, "w").write("\n".join(out) + "\n")
 print("\n".join(out))

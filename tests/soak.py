@@ -32,15 +32,16 @@ shapes = [(4096, 3072), (4096, 3072), (2048, 2048), (1921, 1081), (1920, 1080), 
           (160, 120), (176, 144), (200, 152), (104, 100), (224, 200),   # round 4: 65 .. 640 tiles with 8-byte rows: encode_frames_kernel
           (2999, 2001), (1923, 1083), (1935, 1080),                     # round 4: odd rows on dword-aligned fetches (kInRaw4) / last pair of 15 columns (natural)
           (1081, 1921), (1009, 700),                                    # ... pairs dealt linearly (68 / 64 pairs per tile row); the others above: one wave per row segment (kInRow)
-          (1921, 1081), (1001, 999), (64, 64), (8, 8), (61, 59), (33, 31), (512, 8), (24, 16)]
+          (1921, 1081), (1001, 999), (64, 64), (8, 8), (61, 59), (33, 31), (512, 8), (24, 16),
+          (32, 32), (40, 24), (16, 16), (80, 80), (120, 120), (128, 120), (72, 72), (64, 64)]   # round 4, second half: the persistent small-frame kernels (decode_mid_kernel, encode_group_kernel)
 t0 = time.time()
 frames_done = 0
 for r in range(a.rounds):
     W, H = shapes[int(rng.integers(0, len(shapes)))]
     per = W * H
     n = int(rng.choice([1, 3, 17, 64, 200, 512, 1024]))
-    if per <= 64 * 64:
-        n = int(rng.choice([1, 7, 1000, 30000, 200000]))     # tiny frames: many per wave
+    if per <= 128 * 128:
+        n = int(rng.choice([1, 7, 1000, 30000, 200000]))     # small frames: many per workgroup, persistent workgroups walk many groups
     n = max(1, min(n, int(9e9 // per)))
     content = str(rng.choice(["noise8", "mixed", "smooth", "flat"]))
     concat = bool(rng.integers(0, 2)) and n * 8 * dv.tiles(W, H) < 2**32

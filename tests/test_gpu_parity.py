@@ -402,7 +402,8 @@ def test_scanners_mark_unvisited_offsets(codec):
 
 
 @pytest.mark.parametrize("W,H,n,mode", [(200, 123, 3, "mixed"), (8, 8, 1, "noise8"), (9, 9, 2, "mixed"),
-                                        (4096, 24, 1, "noise8"), (1, 1, 1, "flat"), (24, 8, 1, "noise8")])
+                                        (4096, 24, 1, "noise8"), (1, 1, 1, "flat"), (24, 8, 1, "noise8"),
+                                        (72, 72, 3, "mixed"), (64, 64, 2, "smooth")])   # (the small-frame decoder: 16-byte pieces from the payload's first byte on)
 def test_decode_reads_nothing_past_stream_bytes(codec, W, H, n, mode):
     """dbde_hip.h: stream_bytes is the READABLE extent.  The stream is placed so that its end falls on
     every residue mod 16 (the payload DMA moves whole 16-byte slots from an aligned-down source; the slot

@@ -3067,6 +3067,10 @@ __device__ __forceinline__ u32x4_t frame_block(const uint8_t *m, uint32_t pay0, 
     u32x4_t q;
     if (o + 16u <= meta) {
         q = *reinterpret_cast<const u32x4_t *>(m + o);
+    } else if ((meta & 15u) == 0u) {                        // T a multiple of 8: payload blocks are blocks of the LDS image as they are
+        // (64x64 encode 0.54 -> 0.58 mixed / 0.57 -> 0.63 incompressible, 128x128 0.61 -> 0.64 / 0.55 -> 0.61; the general path's reads
+        // as plain loads instead of the spelled-out three + wait: no difference)
+        q = *reinterpret_cast<const u32x4_t *>(pay + (o - meta));
     } else {
         const int po = (int)o - (int)meta;                  // may be negative in the straddling block
         const uint32_t a = (uint32_t)((int)pay0 + po), a4 = a & ~3u;

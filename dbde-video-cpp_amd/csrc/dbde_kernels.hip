@@ -2814,7 +2814,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
     constexpr int NW = THREADS / 64;
     __shared__ uint32_t s_tot[2][NW];
     __shared__ uint32_t s_incl[2][THREADS];
-    // a payload slot per lane (64 bytes + what the last row's three dwords read past them), and in the same memory, later
+    // a payload slot per lane (five 16-byte pieces: up to 3 bytes of alignment + 64 of payload; the last row's three dwords end
+    // at byte 68), and in the same memory, later
     // in a group's life, the image of the group's pixels (STAGED: THREADS / T frames of T tiles, 16 bytes of alignment)
     constexpr uint32_t kMidSlot = 80u;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[THREADS * kMidSlot];
@@ -2908,23 +2909,30 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
         // (unpack_tile_from_lds: three aligned dwords + v_alignbyte per row).  The one wait behind the loads is a wait the
         // whole loop body shares: behind it the prefetched words of the next group have arrived as well (they were asked
         // for earlier), and nothing behind the group's stores waits for memory again.
+        // (The pieces start at the dword boundary in front of the payload: frames of an odd tile count have their payload at
+        // 2 mod 4, and 16-byte loads from there ran a fifth slower per tile than from dword boundaries -- 72x72, 88x72, 104x72,
+        // 88x56 against 80x64, 72x64, 96x64, 80x72, profiles/r04b_parity.sh.  The up to three bytes in front are the end of the
+        // frame's minimum array; a tile of even depth may need one piece more, five for depth 8.)
         const uint8_t *pay = p.stream + foff + need + 8ull * prefix;
-        const uint32_t npc_all = (d + 1u) >> 1;
+        const uint32_t poff = (uint32_t)(reinterpret_cast<uintptr_t>(pay) & 3u);
+        const uint8_t *psrc = pay - poff;
+        const uint32_t npc_all = (8u * d + poff + 15u) >> 4;
 #ifdef DBDE_MID_ABLATE_LOADS
         const bool whole = false;
 #else
-        const bool whole = ok && d != 0u && pay + 16u * npc_all <= s_end;   // every piece lies inside the readable extent
+        const bool whole = ok && d != 0u && psrc + 16u * npc_all <= s_end;   // every piece lies inside the readable extent
 #endif
         const uint32_t npc = whole ? npc_all : 0u;
-        u32x4_t q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
-        if (npc > 0u) __builtin_memcpy(&q0, pay, 16);
-        if (npc > 1u) __builtin_memcpy(&q1, pay + 16, 16);
-        if (npc > 2u) __builtin_memcpy(&q2, pay + 32, 16);
-        if (npc > 3u) __builtin_memcpy(&q3, pay + 48, 16);
+        u32x4_t q0 = {0u, 0u, 0u, 0u}, q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+        if (npc > 0u) __builtin_memcpy(&q0, psrc, 16);
+        if (npc > 1u) __builtin_memcpy(&q1, psrc + 16, 16);
+        if (npc > 2u) __builtin_memcpy(&q2, psrc + 32, 16);
+        if (npc > 3u) __builtin_memcpy(&q3, psrc + 48, 16);
+        if (npc > 4u) __builtin_memcpy(&q4, psrc + 64, 16);
         // First look at anything this iteration asked for.  (Left to itself the scheduler moves the consumers of the
         // prefetched words up to their loads to shorten live ranges -- a wait for the round trip that was to be hidden,
         // seen in the listing -- and a look at them BEHIND the stores would wait for the stores too.)
-        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3),
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4),
                           "+v"(m_nxt.d), "+v"(m_nxt.mn), "+v"(m_nxt.nb), "+v"(m_nxt.nm), "+v"(m_nxt.n64), "+v"(foff_nn),
                           "+v"(h_field), "+v"(h_index), "+v"(h_elapsed) :: "memory");
         const uint32_t slot = kMidSlot * tid;
@@ -2934,16 +2942,17 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
             if (npc > 1u) sl[1] = q1;
             if (npc > 2u) sl[2] = q2;
             if (npc > 3u) sl[3] = q3;
+            if (npc > 4u) sl[4] = q4;
         }
 #ifndef DBDE_MID_ABLATE_LOADS
         if (ok && d != 0u && !whole) {   // the stream's last bytes: nothing past the extent
-            for (uint32_t b = 0; b < 8u * d; b++) s_lds[slot + b] = pay[b];
+            for (uint32_t b = 0; b < 8u * d; b++) s_lds[slot + poff + b] = pay[b];
         }
 #endif
         uint32_t v[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = 0;
-        if (ok) unpack_tile_from_lds<false>(s_lds, slot, d, mn, v);   // (a flat tile: the minimum, whatever the slot holds)
+        if (ok) unpack_tile_from_lds<false>(s_lds, slot + poff, d, mn, v);   // (a flat tile: the minimum, whatever the slot holds)
         if (STAGED) lds_barrier();   // the payload slots and the image of the group's pixels share the memory
         if (ok) {   // (a rejected frame's image stays untouched, dbde_util.cpp:296-303)
             uint8_t *dst = p.images + (size_t)f * p.frame_pixels + tile_off;

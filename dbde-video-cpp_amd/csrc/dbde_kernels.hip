@@ -25,6 +25,9 @@
 #ifndef DBDE_LINE_ALIGNED_STORES
 #define DBDE_LINE_ALIGNED_STORES 1   // A/B switch: 0 = payload stores start at the wave's first 16-byte boundary
 #endif
+#ifndef DBDE_UNALIGNED_OUT_WORDS
+#define DBDE_UNALIGNED_OUT_WORDS 0   // A/B switch: 1 = frames at any alignment leave word by word (8-byte stores at whatever address)
+#endif
 #ifndef DBDE_NT
 #define DBDE_NT 1   // non-temporal hint on the streamed-once traffic (pixels, payload, decoded images)
 #endif
@@ -955,7 +958,68 @@ __device__ __forceinline__ void store_wave_part(const EncParams &p, const ChunkR
             *reinterpret_cast<uint64_t *>(dst + 8ull * q) = pay[swz ? swzq8(q) : q];
         }
     } else {
+#if DBDE_UNALIGNED_OUT_WORDS   // (round 1-4a form: one 8-byte store per word at whatever address it has)
         for (uint32_t q = lane; q < wtot; q += 64u) store_u64_any(dst + 8ull * q, pay[swz ? swzq8(q) : q]);
+#else
+        // Any alignment of the frame (tile counts that are no multiple of 4, odd slot strides or bases): per-lane 8-byte stores
+        // at 2 or 4 mod 8 cost the encoder 12-15 % (1008x1000 0.63 against 1008x1008 0.72, profiles/r04b_unaligned.sh).  The
+        // wave's byte range leaves as ALIGNED 16-byte blocks instead, whole cache lines per store instruction as above; a
+        // block is bytes r .. r + 15 of three consecutive payload words (r = how far the range's blocks sit off its words,
+        // the same for the whole wave: four v_alignbyte), the partial block at either end takes its bytes in 8 / 4 / 2 / 1
+        // pieces (the neighbouring wave or frame field owns the rest of it).
+        const uint32_t nbytes = 8u * wtot;
+        if (nbytes != 0u) {
+            const uint32_t sft = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+            uint8_t *blk0 = dst - sft;                                   // 16-byte aligned
+            const uint32_t n_blocks = (sft + nbytes + 15u) >> 4;
+            const uint32_t r = (16u - sft) & 7u;
+            auto word = [&](uint32_t q) -> uint64_t { return pay[swz ? swzq8(q) : q]; };
+            const uint32_t h = (uint32_t)((128u - (uint32_t)(reinterpret_cast<uintptr_t>(blk0) & 127u)) & 127u) >> 4;
+            for (int base = h ? (int)h - 64 : 0; base < (int)n_blocks; base += 64) {
+                const int j = base + lane;
+                if (j < 0 || j >= (int)n_blocks) continue;
+                const int off = 16 * j - (int)sft;                       // payload byte the block starts with (< 0: the first block)
+                const bool first = off < 0, last = off + 16 > (int)nbytes;
+                const uint32_t qa = first ? 0u : (uint32_t)off >> 3;
+                const uint32_t rr = first ? 0u : r;
+                // (words behind the wave's last one are read and not used: they lie inside the workgroup's payload images)
+                // (two words, the block's low half, then the third: six dwords held at once made the instance spill)
+                u32x4_t o;
+                const bool low = rr < 4u;
+                {
+                    const uint64_t wa = word(qa), wb = word(qa + 1u);
+                    const uint32_t d0 = (uint32_t)wa, d1 = (uint32_t)(wa >> 32), d2 = (uint32_t)wb, d3 = (uint32_t)(wb >> 32);
+                    o[0] = __builtin_amdgcn_alignbyte(low ? d1 : d2, low ? d0 : d1, rr);
+                    o[1] = __builtin_amdgcn_alignbyte(low ? d2 : d3, low ? d1 : d2, rr);
+                    o[2] = low ? d2 : d3;       // (the low operand of the next one)
+                    o[3] = d3;
+                }
+                {
+                    const uint64_t wc = word(qa + 2u);
+                    const uint32_t d4 = (uint32_t)wc, d5 = (uint32_t)(wc >> 32);
+                    const uint32_t d3 = o[3];
+                    o[2] = __builtin_amdgcn_alignbyte(low ? d3 : d4, o[2], rr);
+                    o[3] = __builtin_amdgcn_alignbyte(low ? d4 : d5, low ? d3 : d4, rr);
+                }
+                if (!first && !last) {
+                    if (DBDE_NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(blk0 + 16ll * j));
+                    else *reinterpret_cast<u32x4_t *>(blk0 + 16ll * j) = o;
+                } else {
+                    // o holds the range's bytes from the block's first valid one on: n of them go to where that one belongs
+                    uint8_t *to = first ? dst : blk0 + 16ll * j;
+                    uint32_t n = (first ? 16u - sft : 16u);
+                    const uint32_t left = nbytes - (first ? 0u : (uint32_t)off);
+                    n = n < left ? n : left;
+                    uint64_t lo = ((uint64_t)o[1] << 32) | o[0];
+                    const uint64_t hi = ((uint64_t)o[3] << 32) | o[2];
+                    if (n & 8u) { store_u64_any(to, lo); to += 8; lo = hi; }
+                    if (n & 4u) { const uint32_t x = (uint32_t)lo; __builtin_memcpy(to, &x, 4); to += 4; lo >>= 32; }
+                    if (n & 2u) { const uint16_t x = (uint16_t)lo; __builtin_memcpy(to, &x, 2); to += 2; lo >>= 16; }
+                    if (n & 1u) *to = (uint8_t)lo;
+                }
+            }
+        }
+#endif
     }
 }
 

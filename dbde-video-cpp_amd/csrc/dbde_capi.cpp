@@ -924,7 +924,7 @@ int dbde_hip_encode_plan(int W, int H, int n_frames, uint64_t image_address, uin
     plan->kernel = pl.kernel;
     plan->input_mode = pl.fast_in ? 0 : (pl.lanes_per_row ? (pl.seg_per_row ? 4 : pl.pairs_per_wave == 63u ? 3 : 1) : 2);
     plan->aligned_out = pl.aligned_out ? 1 : 0;
-    plan->threads = (pl.kernel == 2 || pl.kernel == 5) ? 256 : (pl.kernel == 3 ? (int32_t)mid_threads_for(g.T) : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u)));
+    plan->threads = (pl.kernel == 2 || pl.kernel == 5) ? 256 : (pl.kernel == 3 ? (int32_t)mid_encode_threads_for(g.T) : (pl.kernel == 4 ? (int32_t)frames_threads_for(g.T) : (int32_t)(kEncChunkTiles / 2u)));
     plan->chunks_per_frame = pl.kernel >= 2 ? 0u : pl.enc_cpf;
     plan->chunk_tiles = pl.kernel >= 2 ? 0u : (pl.seg_per_row ? 2u * (pl.seg_q + (pl.seg_rem ? 1u : 0u)) * (kEncChunkTiles / 128u) : pl.lanes_per_row ? 2u * pl.pairs_per_wave * (kEncChunkTiles / 128u) : kEncChunkTiles);
     plan->n_chunks = pl.kernel >= 2 ? 0ull : pl.n_chunks64;

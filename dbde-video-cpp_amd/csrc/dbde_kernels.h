@@ -171,6 +171,7 @@ int encode_blocks_per_cu();
 // workgroup as fit (mid_threads_for), no workspace.
 hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t s);
 uint32_t mid_threads_for(uint32_t T, uint32_t max_threads = 1024u);
+uint32_t mid_encode_threads_for(uint32_t T);
 uint32_t mid_decode_threads_for(uint32_t T);   // the decoder's choice (persistent workgroups: smaller ones, more of them per CU)
 // (persistent workgroups, n_cu * 2048 / threads of them; n_cu = 0: three, for tests of the pipelined loop on small batches)
 hipError_t launch_decode_mid(const struct DecParams &p, uint32_t n_frames, uint32_t n_cu, hipStream_t s);

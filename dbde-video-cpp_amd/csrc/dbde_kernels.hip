@@ -1740,6 +1740,12 @@ uint32_t mid_threads_for(uint32_t T, uint32_t max_threads) {
     return best;
 }
 
+#ifndef DBDE_MID_ENCODE_MAX_THREADS
+#define DBDE_MID_ENCODE_MAX_THREADS 1024
+#endif
+uint32_t mid_encode_threads_for(uint32_t T) {
+    return mid_threads_for(T, T <= (unsigned)DBDE_MID_ENCODE_MAX_THREADS ? (unsigned)DBDE_MID_ENCODE_MAX_THREADS : 1024u);
+}
 uint32_t mid_decode_threads_for(uint32_t T) {
     return mid_threads_for(T, T <= (unsigned)DBDE_MID_DECODE_MAX_THREADS ? (unsigned)DBDE_MID_DECODE_MAX_THREADS : 1024u);
 }
@@ -1748,7 +1754,7 @@ hipError_t launch_encode_mid(const EncParams &p, uint32_t n_frames, hipStream_t 
     EncParams q = p;
     q.n_chunks = n_frames;
     q.chunks_per_frame = 1u;     // write_frame_fields: the one "chunk" is the frame's first and last
-    const uint32_t th = mid_threads_for(p.T), per_wg = th / p.T;
+    const uint32_t th = mid_encode_threads_for(p.T), per_wg = th / p.T;
     const dim3 grid((n_frames + per_wg - 1u) / per_wg);
     if (th == 256u) hipLaunchKernelGGL(encode_mid_kernel<256>, grid, dim3(256), 0, s, q);
     else if (th == 512u) hipLaunchKernelGGL(encode_mid_kernel<512>, grid, dim3(512), 0, s, q);
@@ -3443,11 +3449,16 @@ hipError_t launch_encode_group(const EncParams &p, uint32_t n_frames, uint32_t n
     return hipGetLastError();
 }
 
-// Threads of the workgroup (256: 512 tile slots, 512: 1024) whole frames of T tiles fill best.
+// Threads of the workgroup (256: 512 tile slots, 512: 1024).  The larger workgroup only for frames that do not fit the
+// smaller one: its barriers span eight waves and two of them fill a CU.  Rounds 3-4a took whichever filled its lanes
+// better; measured (profiles/r04b_gain.sh, mixed / incompressible): 90 tiles, eleven frames on 512 threads (97 % full) 0.40 ->
+// five on 256 (88 %) 0.50; 110 tiles 0.42 -> 0.49 / 0.415 -> 0.50; 132 tiles (90 % -> 77 %) 0.44 -> 0.49 / 0.41 -> 0.50; 144 tiles
+// 0.56 -> 0.60 / 0.51 -> 0.59; 300 tiles (88 % -> 59 %: one frame per workgroup) 0.51 -> 0.51 / 0.48 -> 0.53; never slower.
+#ifndef DBDE_FRAMES_512_FROM
+#define DBDE_FRAMES_512_FROM 513   // A/B switch: smallest frame (tiles) that takes the 512-thread workgroup
+#endif
 uint32_t frames_threads_for(uint32_t T) {
-    if (T > 512u) return 512u;
-    const uint32_t u256 = (512u / T) * T, u512 = (1024u / T) * T;
-    return 2u * u256 >= u512 ? 256u : 512u;      // (equal fill: the smaller workgroup, more of them per CU)
+    return T >= (unsigned)DBDE_FRAMES_512_FROM ? 512u : 256u;
 }
 
 hipError_t launch_encode_frames(const EncParams &p, uint32_t n_frames, hipStream_t s) {

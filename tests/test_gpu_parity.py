@@ -893,7 +893,7 @@ def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workg
                                    (520, 8, 30), (9, 600, 25), (180, 180, 7), (130, 121, 1), (65, 64, 513),
                                    # round 4, the staged whole-frame kernels (8-byte rows): odd tile counts, rows below the image
                                    # repeated (H % 8 != 0), one frame per workgroup, a last workgroup that is part empty
-                                   (72, 72, 7), (104, 100, 33), (200, 150, 19), (168, 161, 10), (224, 200, 5), (176, 144, 1),
+                                   (72, 72, 7), (200, 168, 7), (104, 100, 33), (200, 150, 19), (168, 161, 10), (224, 200, 5), (176, 144, 1),
                                    (520, 65, 9), (8, 5200, 3)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
 def test_mid_frames_many_per_workgroup(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, mode):

@@ -612,6 +612,9 @@ int dbde_hip_encode_frames(dbde_hip_ctx *ctx, const uint8_t *d_images, int W, in
 // 225 0.48 -> 0.40 (incompressible 0.53 -> 0.475), 240 0.40 -> 0.315, 256 0.416 -> 0.344 (incompressible 0.414 -> 0.429).
 #define DBDE_MID_DECODE_TILES 256
 #endif
+#ifndef DBDE_MID_DECODE_TILES_UNSTAGED
+#define DBDE_MID_DECODE_TILES_UNSTAGED 768
+#endif
 #ifndef DBDE_STAGED_FILL
 // Percent of a workgroup's 512 tile slots that whole tile rows must fill for the staged decode path.  A workgroup's time
 // hardly depends on how many of its slots are used, so empty slots are lost throughput -- but tile-by-tile stores
@@ -687,6 +690,12 @@ static DecPlan plan_decode(const Geometry &g, int W, int n_frames, uintptr_t ib,
     pl.fused = !pl.self_index && pl.n_chunks64 <= 4ull * (uint64_t)n_cu && !(exp_flags & 8u);
     // tiny frames (the tile-level entry points, thumbnails) and those just above: whole frames per wave / per workgroup
     pl.kernel = g.T <= (unsigned)DBDE_MID_DECODE_TILES ? 3 : 0;
+    // ... and larger frames whose chunks would store tile by tile (rows that are not 8-byte aligned and whole-tile-row chunks
+    // that do not fit the staged image): one frame per 512- or 1024-thread workgroup of the same kernel beats two chunks per
+    // frame + the index kernel -- 180x180 (529 tiles) 0.25 -> 0.33 mixed / 0.28 -> 0.37 incompressible, 130x121 0.37 -> 0.39 / 0.47,
+    // 220x215 (756) 0.36 -> 0.39 / 0.39 -> 0.46; not at 1024 tiles (250x250: 0.51 -> 0.44), not where the chunks stage
+    // (300x200: 0.59 -> 0.42) -- profiles/r04b_gain.sh
+    if (img_mode == 2 && g.T <= (unsigned)DBDE_MID_DECODE_TILES_UNSTAGED) pl.kernel = 3;
 #ifndef DBDE_NO_FRAMES
     if ((exp_flags & 256u) && g.T > 64u && g.T <= (unsigned)DBDE_FRAMES_DECODE_TILES && frames_geometry(g, W, ib)) pl.kernel = 4;
 #endif

@@ -890,7 +890,7 @@ def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workg
 
 
 @pytest.mark.parametrize("W,H,n", [(72, 72, 200), (96, 96, 150), (128, 128, 64), (160, 120, 90), (71, 73, 100), (176, 144, 41),
-                                   (520, 8, 30), (9, 600, 25), (180, 180, 7), (130, 121, 1), (65, 64, 513),
+                                   (520, 8, 30), (9, 600, 25), (180, 180, 7), (130, 121, 1), (150, 150, 40), (220, 215, 9), (65, 64, 513),
                                    # round 4, the staged whole-frame kernels (8-byte rows): odd tile counts, rows below the image
                                    # repeated (H % 8 != 0), one frame per workgroup, a last workgroup that is part empty
                                    (72, 72, 7), (200, 168, 7), (104, 100, 33), (200, 150, 19), (168, 161, 10), (224, 200, 5), (176, 144, 1),

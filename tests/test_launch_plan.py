@@ -111,6 +111,18 @@ def test_small_frames(W, H, T, enc, dec, threads):
     assert dv.encode_plan(W, H, 100000, slot_stride=0)["kernel"] in (PERSISTENT, SMALL)
 
 
+def test_mid_size_frames_that_would_store_tile_by_tile_take_the_small_frame_decoder():
+    """257 .. 768 tiles, rows that are not 8-byte aligned, whole-tile-row chunks that do not fit the staged image: one frame
+    per 512- or 1024-thread workgroup of decode_mid_kernel instead of two chunks per frame + the index kernel (measured);
+    not where the chunks stage their pixels, not at 1024 tiles."""
+    for (W, H) in [(130, 121), (150, 150), (180, 180), (220, 215)]:
+        d = dv.decode_plan(W, H, 100000)
+        assert d["kernel"] == MID and d["threads"] in (512, 1024), (W, H, d)
+    assert dv.decode_plan(250, 250, 100000)["kernel"] == 0           # 1024 tiles: the chunk decoder
+    assert dv.decode_plan(300, 200, 100000)["kernel"] == 0           # staged chunks (13 tile rows of 38 tiles)
+    assert dv.decode_plan(160, 120, 100000)["kernel"] == 0           # 16-byte rows: direct stores
+
+
 def test_index_forms_follow_the_batch():
     assert dv.decode_plan(200, 123, 13)["index_mode"] == SELF                 # few small frames: workgroups index themselves
     assert dv.decode_plan(1024, 768, 6)["index_mode"] == FUSED                # 144 chunks fit the device: fused

@@ -2867,13 +2867,17 @@ struct MidMeta {
 #ifndef DBDE_MID_NT
 #define DBDE_MID_NT DBDE_NT   // A/B switch: the staged image leaves with non-temporal stores
 #endif
+#ifndef DBDE_MID_STAGE_ROWS
+#define DBDE_MID_STAGE_ROWS 4   // image rows (and bases) that are multiples of this many bytes take the staged form (A/B: 8 = the round-4b start)
+#endif
 #ifndef DBDE_MID_NO_STAGE
 #define DBDE_MID_NO_STAGE 0   // A/B switch: 1 = tile rows stored straight from the registers at every width
 #endif
 #ifndef DBDE_MID_WAVES
 #define DBDE_MID_WAVES 6   // (the register allocator's target; the 256-thread instance comes out at 64 VGPRs = eight waves per SIMD without scratch, asked for eight it spills)
 #endif
-// STAGED (8-byte aligned image rows: W % 8 == 0 and an 8-byte aligned base): the group's frames are ONE contiguous byte range
+// STAGED (4-byte aligned image rows: W % 4 == 0 and a 4-byte aligned base; W % 8 == 0: aligned 8-byte LDS stores, else two
+// dwords per tile row and one for the row's last tile): the group's frames are ONE contiguous byte range
 // of the output (frames follow each other in the batch).  Eight 8-byte stores per lane at a stride of W scatter a wave's
 // store over a dozen partial cache lines -- with the payload loads ablated the kernel still took 0.50 of its 0.72 ms on
 // 72x72 frames, without the stores 0.34 -- so the tile rows go into an LDS image of that range (aligned ds_write_b64,
@@ -3036,7 +3040,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
                 if (lo == 0x12345678u && hi == 0x9ABCDEF0u) {
 #else
                 if (STAGED) {
-                    if ((uint32_t)r < rv) lds_store_u64_any(s_lds, px0 + (uint32_t)r * Wu, lo, hi);   // (8-byte aligned)
+                    if ((uint32_t)r < rv) {   // (rows of W % 8 == 0: 8-byte aligned; of W % 8 == 4: two dwords, the row's last tile one)
+                        const uint32_t a = px0 + (uint32_t)r * Wu;
+                        if ((Wu & 7u) == 0u) lds_store_u64_any(s_lds, a, lo, hi);
+                        else {
+                            *reinterpret_cast<uint32_t *>(s_lds + a) = lo;
+                            if (rm == 8u) *reinterpret_cast<uint32_t *>(s_lds + a + 4u) = hi;
+                        }
+                    }
                 } else if ((uint32_t)r < rv) {   // only the valid region is written (dbde_util.cpp:281-289)
 #endif
                     uint8_t *row = dst + (size_t)r * Wu;
@@ -3056,29 +3067,31 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 4 : DBDE_MID_WAVES) void
             const uint32_t P = (uint32_t)p.frame_pixels;
             const uint32_t nfr = n_frames - g * fpw < fpw ? n_frames - g * fpw : fpw;      // frames of this group
             uint8_t *g0 = p.images + (size_t)(g * fpw) * p.frame_pixels;                   // its first byte in the output
-            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 15u);         // 0 or 8
+            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(g0) & 15u);         // a multiple of 4
             const uint32_t nbytes = nfr * P;
-            if (s_bad[par] == 0u) {   // every frame decoded: aligned 16-byte blocks, an 8-byte half at either end
+            if (s_bad[par] == 0u) {   // every frame decoded: aligned 16-byte blocks, the partial one at either end dword by dword
                 const uint32_t n_blocks = (sh + nbytes + 15u) >> 4;
                 for (uint32_t j = tid; j < n_blocks; j += (uint32_t)THREADS) {
                     uint8_t *dst = g0 - sh + 16ull * j;
-                    const bool upper_only = j == 0u && sh != 0u, lower_only = 16u * j + 16u > sh + nbytes;
-                    if (!upper_only && !lower_only) {
+                    if (16u * j >= sh && 16u * j + 16u <= sh + nbytes) {
                         const u32x4_t q = *reinterpret_cast<const u32x4_t *>(s_lds + 16u * j);
 #ifdef DBDE_MID_ABLATE_STORES
                         if (q[0] != 0x12345678u || q[3] != 0x9ABCDEF1u) continue;
 #endif
                         if (DBDE_MID_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t *>(dst));
                         else *reinterpret_cast<u32x4_t *>(dst) = q;
-                    } else if (!(upper_only && lower_only)) {
-                        const uint32_t o = upper_only ? 8u : 0u;
-                        *reinterpret_cast<uint64_t *>(dst + o) = *reinterpret_cast<const uint64_t *>(s_lds + 16u * j + o);
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 4u; k++) {
+                            const uint32_t o = 16u * j + 4u * k;
+                            if (o >= sh && o < sh + nbytes) *reinterpret_cast<uint32_t *>(dst + 4u * k) = *reinterpret_cast<const uint32_t *>(s_lds + o);
+                        }
                     }
                 }
-            } else {                          // a rejected frame's image stays untouched: 8 bytes at a time, frame by frame
-                for (uint32_t u = tid; 8u * u < nbytes; u += (uint32_t)THREADS) {
-                    const uint32_t o = 8u * u;
-                    if (s_ok[o / P]) *reinterpret_cast<uint64_t *>(g0 + o) = *reinterpret_cast<const uint64_t *>(s_lds + sh + o);
+            } else {                          // a rejected frame's image stays untouched: 4 bytes at a time, frame by frame
+                for (uint32_t u = tid; 4u * u < nbytes; u += (uint32_t)THREADS) {
+                    const uint32_t o = 4u * u;
+                    if (s_ok[o / P]) *reinterpret_cast<uint32_t *>(g0 + o) = *reinterpret_cast<const uint32_t *>(s_lds + sh + o);
                 }
             }
         }
@@ -3101,7 +3114,7 @@ hipError_t launch_decode_mid(const DecParams &p, uint32_t n_frames, uint32_t n_c
     const uint32_t th = mid_decode_threads_for(p.T), per_wg = th / p.T;
     uint32_t groups = (n_frames + per_wg - 1u) / per_wg;
     // 8-byte aligned image rows: pixels staged in LDS, aligned 16-byte stores (decode_mid_kernel<., true>)
-    const bool staged = p.W % 8 == 0 && (reinterpret_cast<uintptr_t>(p.images) & 7u) == 0u && !DBDE_MID_NO_STAGE;
+    const bool staged = p.W % DBDE_MID_STAGE_ROWS == 0 && (reinterpret_cast<uintptr_t>(p.images) & (DBDE_MID_STAGE_ROWS - 1)) == 0u && !DBDE_MID_NO_STAGE;
     auto go = [&](auto kernel, uint32_t threads) {
         // persistent: as many workgroups as the device holds (n_cu = 0, tests: three, so that small batches walk the
         // pipelined loop too)

@@ -861,7 +861,9 @@ def test_seeded_fuzz_against_oracle(codec, oracle):
                                    (7, 300, 33), (61, 59, 129),
                                    # round 4, the persistent small-frame encoder (8-byte rows, frames whole 16-byte blocks): 16, 15
                                    # (rows below the image repeated) and 4 tiles a frame, a last group that is part empty
-                                   (32, 32, 333), (40, 20, 100), (16, 16, 1000)])
+                                   (32, 32, 333), (40, 20, 100), (16, 16, 1000),
+                                   # rows of 4 mod 8 bytes: the staged decoder with two dwords per tile row, one for the row's last tile
+                                   (20, 20, 300), (60, 60, 77), (36, 44, 100), (12, 9, 500)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
 def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, mode):
     """Frames of at most 64 tiles (the reference's randomized test is 1024 single-tile frames, dbde_util_test.cpp:66-96):
@@ -893,7 +895,7 @@ def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workg
                                    (520, 8, 30), (9, 600, 25), (180, 180, 7), (130, 121, 1), (150, 150, 40), (220, 215, 9), (65, 64, 513),
                                    # round 4, the staged whole-frame kernels (8-byte rows): odd tile counts, rows below the image
                                    # repeated (H % 8 != 0), one frame per workgroup, a last workgroup that is part empty
-                                   (72, 72, 7), (200, 168, 7), (104, 100, 33), (200, 150, 19), (168, 161, 10), (224, 200, 5), (176, 144, 1),
+                                   (72, 72, 7), (200, 168, 7), (100, 75, 50), (104, 100, 33), (200, 150, 19), (168, 161, 10), (224, 200, 5), (176, 144, 1),
                                    (520, 65, 9), (8, 5200, 3)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
 def test_mid_frames_many_per_workgroup(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, mode):
@@ -961,7 +963,7 @@ def codec_staged_decode(dv):
 
 
 @pytest.mark.parametrize("which", ["default", "staged", "three_workgroups"])
-@pytest.mark.parametrize("W,H,n", [(72, 72, 50), (160, 120, 23), (96, 96, 61), (200, 150, 9)])
+@pytest.mark.parametrize("W,H,n", [(72, 72, 50), (160, 120, 23), (96, 96, 61), (200, 150, 9), (60, 60, 40), (100, 76, 30)])
 def test_staged_frame_decoder_takes_any_offsets_and_rejects_like_the_reference(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, which):
     codec = {"default": codec, "staged": codec_staged_decode, "three_workgroups": codec_three_workgroups}[which]
     """decode_frames_kernel: frames wherever they lie (concatenated: every alignment mod 16; a stream base that is odd), a

@@ -496,7 +496,7 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
     pl.n_chunks64 = (uint64_t)n_frames * pl.enc_cpf;
     pl.aligned_out = ((out & 7u) == 0) && (g.T % 4 == 0) && (slot_stride % 8 == 0);
     pl.kernel = 0;
-    const bool blocks16 = W % 8 == 0 && g.pixels % 16 == 0 && (images & 15u) == 0 && (out & 15u) == 0 && slot_stride % 16 == 0;
+    const bool rows4 = W % 4 == 0 && (images & 3u) == 0 && (out & 15u) == 0 && slot_stride % 16 == 0;
     if (false) {}
 #ifndef DBDE_NO_GROUP
     // Small frames in slots, 8-byte aligned rows, frames and buffers whole 16-byte blocks: persistent workgroups, the next
@@ -506,7 +506,8 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
     // 0.50 / 0.49 -> 0.56.  Where whole frames leave lanes empty the two-tiles-per-lane kernel below keeps mixed content
     // (96x96, one frame of 144 tiles per workgroup: 0.51 -> 0.42; 128x128 at full fill 0.62 -> 0.56, incompressible 0.54 ->
     // 0.58), and single-tile frames keep the per-wave kernel (8x8: 0.17 -> 0.09, 256 frame images per workgroup).
-    else if (slot_stride != 0 && blocks16 && g.T >= 4u &&
+    // (rows and image bases of 4-byte multiples suffice since the round's last hours: DESIGN 4.1)
+    else if (slot_stride != 0 && rows4 && g.T >= 4u &&
              (g.T <= 64u || (g.T <= (unsigned)DBDE_GROUP_ENCODE_TILES && (256u / g.T) * g.T * 10u >= 256u * 9u))) pl.kernel = 5;
 #endif
     else if (g.T <= 64u && slot_stride != 0) pl.kernel = 2;     // tiny frames in slots: several frames per wave, nothing shared

@@ -3332,6 +3332,9 @@ __global__ __launch_bounds__(THREADS) void encode_frames_kernel(EncParams p) {
 // One slot per frame (nothing is shared between frames: no workspace, nothing to wait for).
 constexpr uint32_t kGroupThreads = 256u;
 
+// ROWS4: rows and bases of 4-byte multiples (the image shifted to agree with global memory mod 16, head / tail dwords, dword
+// tile rows); else rows of 8-byte multiples and frames / bases of whole 16-byte blocks (shift 0 throughout: 3 % faster there)
+template <bool ROWS4>
 __global__ __launch_bounds__(kGroupThreads, 4) void encode_group_kernel(EncParams p) {
     constexpr uint32_t TH = kGroupThreads, NW = TH / 64u, kWords = TH * 8u;       // 8 payload words (64 pixels) per tile slot
     extern __shared__ __attribute__((aligned(16))) uint8_t s_meta[];               // (256 / T) x the frame's first 32 + 2T bytes, rounded up to 16
@@ -3348,15 +3351,37 @@ __global__ __launch_bounds__(kGroupThreads, 4) void encode_group_kernel(EncParam
     uint32_t tx;
     const uint32_t ty = div_magic(t, p.w, p.magic_w, tx);
     const uint32_t px = (fl < fpw ? fl * P : 0u) + 8u * tx;
+    const uint32_t rm = W - 8u * tx < 8u ? W - 8u * tx : 8u;          // valid columns: 8, or 4 in the last tile of rows of 4 mod 8 bytes
+    const bool rows8 = !ROWS4 || ((W & 7u) == 0u && (reinterpret_cast<uintptr_t>(p.images) & 7u) == 0u);   // (uniform) tile rows are aligned 8-byte reads
 
-    auto fetch = [&](uint32_t g, uint32_t b) {   // the pixels of group g -> buffer b, whole 16-byte blocks, nothing waited for
+    // The pixels of group g -> buffer b, nothing waited for.  The image is placed where LDS and global addresses agree mod 16
+    // (bases and rows are multiples of 4 bytes, not necessarily of 16): every 16-byte block that lies inside the group's
+    // byte range travels as one, the up to three dwords in front of the first and behind the last of them as dwords --
+    // nothing outside the range is read.
+    auto group_shift = [&](uint32_t g) -> uint32_t {
+        return ROWS4 ? (uint32_t)((reinterpret_cast<uintptr_t>(p.images) + (size_t)(g * fpw) * P) & 15u) : 0u;
+    };
+    auto fetch = [&](uint32_t g, uint32_t b) {
         if (g >= n_groups) return;
         const uint32_t nfr = n_frames - g * fpw < fpw ? n_frames - g * fpw : fpw;
         const uint8_t *src = p.images + (size_t)(g * fpw) * P;
-        const uint32_t n16 = nfr * (P >> 4);
-        for (uint32_t i = tid; i < n16; i += TH)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16ull * i),
-                                             (__attribute__((address_space(3))) void *)(&s_buf[b][2u * (i - lane)]), 16, 0, DBDE_NT ? 2 : 0);
+        const uint32_t sh = group_shift(g), total = sh + nfr * P;
+        const uint8_t *src0 = src - sh;                              // 16-byte aligned
+        const uint32_t j0 = sh ? 1u : 0u, j1 = total >> 4;           // whole blocks [j0, j1)
+        for (uint32_t i = tid; j0 + i < j1; i += TH)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + 16ull * (j0 + i)),
+                                             (__attribute__((address_space(3))) void *)(&s_buf[b][2u * (j0 + i - lane)]), 16, 0, DBDE_NT ? 2 : 0);
+        uint8_t *img = reinterpret_cast<uint8_t *>(s_buf[b]);
+        if (ROWS4 && wave == 0u) {
+            const uint32_t head = sh ? (16u - sh) >> 2 : 0u;         // dwords in front of the first whole block
+            if (lane < head)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4u * lane),
+                                                 (__attribute__((address_space(3))) void *)(img + sh), 4, 0, 0);
+            const uint32_t tail = (total & 15u) >> 2;                // ... behind the last one
+            if (lane < tail)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + 16ull * j1 + 4u * lane),
+                                                 (__attribute__((address_space(3))) void *)(img + 16u * j1), 4, 0, 0);
+        }
     };
     auto pref = [&](uint32_t x) -> uint32_t {    // inclusive prefix of the depths over the workgroup at lane x
         uint32_t a = s_incl[x];
@@ -3371,6 +3396,7 @@ __global__ __launch_bounds__(kGroupThreads, 4) void encode_group_kernel(EncParam
     lds_barrier();
     for (; g < n_groups; g += G, cur ^= 1u) {
         fetch(g + G, cur ^ 1u);                  // in flight until this group's frames are ready to leave
+        const uint32_t sh_cur = group_shift(g);
         const uint32_t nfr = n_frames - g * fpw < fpw ? n_frames - g * fpw : fpw;
         const bool active = fl < nfr;
         const uint32_t f = g * fpw + fl;
@@ -3382,8 +3408,16 @@ __global__ __launch_bounds__(kGroupThreads, 4) void encode_group_kernel(EncParam
             for (int r = 0; r < 8; r++) {
                 uint32_t yy = 8u * ty + (uint32_t)r;
                 yy = yy < (uint32_t)p.H ? yy : (uint32_t)p.H - 1u;
-                const uint2 q = *reinterpret_cast<const uint2 *>(img + px + yy * W);
-                v[2 * r] = q.x; v[2 * r + 1] = q.y;
+                const uint32_t a = sh_cur + px + yy * W;
+                if (rows8) {
+                    const uint2 q = *reinterpret_cast<const uint2 *>(img + a);
+                    v[2 * r] = q.x; v[2 * r + 1] = q.y;
+                } else {   // 4-byte aligned rows; the row's last tile of a width of 4 mod 8: the last valid pixel repeated (dbde_util.cpp:116-128)
+                    const uint32_t lo = *reinterpret_cast<const uint32_t *>(img + a);
+                    v[2 * r] = lo;
+                    v[2 * r + 1] = rm == 8u ? *reinterpret_cast<const uint32_t *>(img + a + 4u) : (lo >> 24) * 0x01010101u;
+                }
+
             }
         }
         uint32_t mn, mx;
@@ -3455,10 +3489,16 @@ hipError_t launch_encode_group(const EncParams &p, uint32_t n_frames, uint32_t n
     const uint32_t meta_bytes = fpw * ((32u + 2u * p.T + 15u) & ~15u);
     const uint32_t groups = (n_frames + fpw - 1u) / fpw;
     // persistent: as many workgroups as the device holds (n_cu = 0, tests: three, so that small batches walk the loop too)
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, encode_group_kernel, (int)kGroupThreads, meta_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-    const uint32_t resident = n_cu ? n_cu * (uint32_t)per_cu : 3u;
-    hipLaunchKernelGGL(encode_group_kernel, dim3(groups < resident ? groups : resident), dim3(kGroupThreads), meta_bytes, s, q);
+    // (whole 16-byte blocks everywhere: the instance without the shifted image)
+    const bool blocks16 = p.W % 8 == 0 && p.frame_pixels % 16 == 0 && (reinterpret_cast<uintptr_t>(p.images) & 15u) == 0u;
+    auto go = [&](auto kernel) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)kGroupThreads, meta_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+        const uint32_t resident = n_cu ? n_cu * (uint32_t)per_cu : 3u;
+        hipLaunchKernelGGL(kernel, dim3(groups < resident ? groups : resident), dim3(kGroupThreads), meta_bytes, s, q);
+    };
+    if (blocks16) go(encode_group_kernel<false>);
+    else go(encode_group_kernel<true>);
     return hipGetLastError();
 }
 

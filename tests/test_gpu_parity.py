@@ -863,7 +863,9 @@ def test_seeded_fuzz_against_oracle(codec, oracle):
                                    # (rows below the image repeated) and 4 tiles a frame, a last group that is part empty
                                    (32, 32, 333), (40, 20, 100), (16, 16, 1000),
                                    # rows of 4 mod 8 bytes: the staged decoder with two dwords per tile row, one for the row's last tile
-                                   (20, 20, 300), (60, 60, 77), (36, 44, 100), (12, 9, 500)])
+                                   (20, 20, 300), (60, 60, 77), (36, 44, 100), (12, 9, 500),
+                                   # ... frames that are no whole 16-byte blocks: the persistent encoder's image shifts from group to group
+                                   (20, 10, 200), (28, 9, 150)])
 @pytest.mark.parametrize("mode", ["noise8", "mixed", "smooth", "flat"])
 def test_tiny_frames_many_per_wave(codec, codec_staged_decode, codec_three_workgroups, oracle, W, H, n, mode):
     """Frames of at most 64 tiles (the reference's randomized test is 1024 single-tile frames, dbde_util_test.cpp:66-96):

@@ -81,7 +81,7 @@ def test_unaligned_image_base_changes_the_form():
 
 @pytest.mark.parametrize("W,H,T,enc,dec,threads", [
     (8, 8, 1, TINY, MID, 256), (64, 64, 64, GROUP, MID, 256),   # (decode: one kernel from single-tile frames up to 256 tiles)
-    (32, 32, 16, GROUP, MID, 256), (16, 16, 4, GROUP, MID, 256), (16, 8, 2, TINY, MID, 256), (20, 20, 9, TINY, MID, 256),
+    (32, 32, 16, GROUP, MID, 256), (16, 16, 4, GROUP, MID, 256), (16, 8, 2, TINY, MID, 256), (20, 20, 9, GROUP, MID, 256), (60, 60, 64, GROUP, MID, 256), (18, 18, 9, TINY, MID, 256),
     # 8-byte aligned rows, frames and buffers whole 16-byte blocks (round 4): whole frames per workgroup, staged through LDS
     # (encode; the decode side keeps decode_mid_kernel -- persistent, software-pipelined from the second half of round 4 --
     # up to 256 tiles and the chunk kernels above: the staged whole-frame decoder measured no faster and is an experiment switch)
@@ -104,8 +104,11 @@ def test_small_frames(W, H, T, enc, dec, threads):
     if dec == MID:
         assert d["threads"] == 256          # the persistent mid decoder: 256-thread workgroups at every fill
     # an image base that is not a multiple of 16 bytes: the staged form does not apply
-    if enc in (FRAMES, GROUP):
+    if enc == FRAMES:
         assert dv.encode_plan(W, H, 100000, slot_stride=slot, image_address=8)["kernel"] in (TINY, MID, PERSISTENT)
+    if enc == GROUP:   # (rows and bases of 4-byte multiples suffice there)
+        assert dv.encode_plan(W, H, 100000, slot_stride=slot, image_address=8)["kernel"] == GROUP
+        assert dv.encode_plan(W, H, 100000, slot_stride=slot, image_address=2)["kernel"] in (TINY, MID, PERSISTENT)
         assert dv.decode_plan(W, H, 100000, image_address=8)["kernel"] in (MID, 0)
     # concatenated frames need each other's sizes: the chunk kernels
     assert dv.encode_plan(W, H, 100000, slot_stride=0)["kernel"] in (PERSISTENT, SMALL)

@@ -390,8 +390,10 @@ int dbde_hip_scatter_plan(int nranks, int rank, int root, const dbde_hip_scatter
 typedef struct dbde_hip_launch_plan {
     int32_t kernel;            /* 0 = chunk kernels (encode: persistent encoder), 1 = encode: one workgroup per chunk
                                   (small launches), 2 = whole frames per wave (encode, T <= 64 tiles), 3 = whole frames per workgroup
-                                  (decode: 1 .. 256 tiles, persistent), 4 = whole frames per workgroup, staged through LDS,
-                                  5 = encode: 1 .. 256 tiles, persistent workgroups, pixels double-buffered */
+                                  (decode: 1 .. 256 tiles, and up to 768 where chunks would store tile by tile; persistent), 4 = whole frames per
+                                  workgroup, staged through LDS,
+                                  5 = encode: 4 .. 64 (and 77 .. 85) tiles in 16-byte aligned slots, rows of 4-byte multiples: persistent
+                                  workgroups, pixels double-buffered */
     int32_t input_mode;        /* encode: 0 = 16-byte aligned rows, 1 = any geometry (W >= 16), 2 = byte by byte (W < 16), 3 = any geometry with dword-aligned fetches (63 tile pairs per wave), 4 = the same with one wave per segment of a tile row */
     int32_t image_mode;        /* decode, kernel 0: 0 = one aligned 16-byte store per lane and image row, 1 = chunks of whole
                                   tile rows staged in LDS (16-byte rows: per chunk, only all-depth-8 chunks stage),

@@ -443,6 +443,9 @@ struct EncPlan {
 #define DBDE_FRAMES_DECODE_TILES 640
 #endif
 // rows 8-byte aligned, frames and base whole 16-byte blocks: what the staged whole-frame kernels take
+#ifndef DBDE_GROUP_ROWS4_ALL
+#define DBDE_GROUP_ROWS4_ALL 1   // rows of 4 mod 8 bytes: every frame up to 256 tiles (the alternative there is encode_mid_kernel: 84x84 0.33 -> 0.44 / 0.30 -> 0.50, 124x124 0.37 -> 0.53 / 0.32 -> 0.59, 100x75 0.325 -> 0.316 / 0.29 -> 0.37)
+#endif
 #ifndef DBDE_GROUP_ENCODE_TILES
 #define DBDE_GROUP_ENCODE_TILES 85    // largest frame (tiles) of the persistent small-frame encoder where frames above 64 tiles fill 90 % of its lanes (77 .. 85 tiles: three frames)
 #endif
@@ -508,7 +511,8 @@ static EncPlan plan_encode(const Geometry &g, int W, int n_frames, uintptr_t ima
     // 0.58), and single-tile frames keep the per-wave kernel (8x8: 0.17 -> 0.09, 256 frame images per workgroup).
     // (rows and image bases of 4-byte multiples suffice since the round's last hours: DESIGN 4.1)
     else if (slot_stride != 0 && rows4 && g.T >= 4u &&
-             (g.T <= 64u || (g.T <= (unsigned)DBDE_GROUP_ENCODE_TILES && (256u / g.T) * g.T * 10u >= 256u * 9u))) pl.kernel = 5;
+             (g.T <= 64u || (g.T <= (unsigned)DBDE_GROUP_ENCODE_TILES && (256u / g.T) * g.T * 10u >= 256u * 9u) ||
+              (DBDE_GROUP_ROWS4_ALL && W % 8 != 0 && g.T <= 256u))) pl.kernel = 5;
 #endif
     else if (g.T <= 64u && slot_stride != 0) pl.kernel = 2;     // tiny frames in slots: several frames per wave, nothing shared
 #ifndef DBDE_NO_FRAMES

@@ -92,7 +92,7 @@ def test_unaligned_image_base_changes_the_form():
     (176, 144, 396, FRAMES, 0, 256),         # one frame in 512 slots = two in 1024 (77 %): the smaller workgroup
     (320, 240, 1200, PERSISTENT, 0, 512),    # above 640 tiles: the chunk kernels
     # rows that are not 8-byte aligned keep the one-tile-per-lane forms
-    (75, 70, 90, MID, MID, 1024), (100, 100, 169, MID, MID, 512), (136, 128, 272, FRAMES, 0, 256), (200, 168, 525, FRAMES, 0, 512),
+    (75, 70, 90, MID, MID, 1024), (100, 100, 169, GROUP, MID, 256), (102, 100, 169, MID, MID, 512), (136, 128, 272, FRAMES, 0, 256), (200, 168, 525, FRAMES, 0, 512),
 ])
 def test_small_frames(W, H, T, enc, dec, threads):
     slot = ((32 + 66 * T + 255) // 256) * 256
